@@ -1,0 +1,180 @@
+"""Host-side descriptions of the balance laws the HIP library carries as C++
+functors.
+
+In the reference a ``BalanceLaw`` is Julia code inlined into every kernel
+(``src/BalanceLaws/interface.jl:37-464``).  A HIP library cannot call Julia per
+node, so each supported law exists twice: here (state counts, one-time host
+initialisation of auxiliary/prognostic state, and the ``(physics_id, iparam,
+dparam)`` parameter block handed across the C ABI) and as a device functor in
+``csrc/physics_*.h``.
+
+``AdvectionDiffusion`` mirrors the reference's test law
+``test/Numerics/DGMethods/advection_diffusion/advection_diffusion_model.jl:92-617``.
+"""
+import numpy as np
+
+from .mesh.grids import _x1, _x2, _x3
+
+EveryDirection, HorizontalDirection, VerticalDirection = 0, 1, 2
+RusanovNumericalFlux, CentralNumericalFluxFirstOrder = 0, 1
+
+PHYSICS_ADVECTION_DIFFUSION = 1
+PHYSICS_DRY_ATMOS = 2
+
+__all__ = [
+    "EveryDirection", "HorizontalDirection", "VerticalDirection",
+    "RusanovNumericalFlux", "CentralNumericalFluxFirstOrder",
+    "InhomogeneousBC", "HomogeneousBC", "AdvectionDiffusion", "Pseudo1D",
+    "ConstantHyperDiffusion",
+]
+
+
+class InhomogeneousBC:
+    """``InhomogeneousBC{O}`` (advection_diffusion_model.jl:62-64)."""
+
+    def __init__(self, order):
+        self.order = order
+
+    @property
+    def bit(self):
+        return 1 << self.order
+
+
+class HomogeneousBC:
+    """``HomogeneousBC{O}`` (advection_diffusion_model.jl:62-63)."""
+
+    def __init__(self, order):
+        self.order = order
+
+    @property
+    def bit(self):
+        return 1 << (self.order + 4)
+
+
+class Pseudo1D:
+    """``Pseudo1D{n, alpha, beta, mu, delta}`` (pseudo1D_advection_diffusion.jl:28-68)."""
+    problem_id = 0
+
+    def __init__(self, n, alpha, beta, mu, delta):
+        self.n = np.asarray(n, dtype=np.float64)
+        self.alpha, self.beta, self.mu, self.delta = alpha, beta, mu, delta
+
+    def dparam(self):
+        d = np.zeros(32)
+        d[0:3] = self.n
+        d[3:7] = [self.alpha, self.beta, self.mu, self.delta]
+        return d
+
+    def init_velocity_diffusion(self, law, aux, coord):
+        n = self.n
+        if law.advection:
+            aux[:, law.off_u:law.off_u + 3, :] = (self.alpha * n)[None, :, None]
+        if law.diffusion:
+            D = (self.beta * n)[:, None] * n[None, :]          # D[i, j] = beta n_i n_j
+            aux[:, law.off_D:law.off_D + 9, :] = D.flatten(order="F")[None, :, None]
+
+    def initial_condition(self, coord, t):
+        n = self.n
+        xn = n[0] * coord[0] + n[1] * coord[1] + n[2] * coord[2]
+        a = xn - self.mu - self.alpha * t
+        return np.exp(-(a * a) / (4 * self.beta * (self.delta + t))) / np.sqrt(1 + t / self.delta)
+
+
+class ConstantHyperDiffusion:
+    """``ConstantHyperDiffusion{dim, dir}`` (periodic_3D_hyperdiffusion.jl:29-63)."""
+    problem_id = 1
+
+    def __init__(self, dim, direction, D):
+        self.dim, self.direction = dim, direction
+        self.D = np.asarray(D, dtype=np.float64).reshape(3, 3)
+
+    def dparam(self):
+        d = np.zeros(32)
+        d[0:9] = self.D.flatten(order="F")
+        d[9], d[10] = self.dim, self.direction
+        return d
+
+    def init_velocity_diffusion(self, law, aux, coord):
+        aux[:, law.off_H:law.off_H + 9, :] = self.D.flatten(order="F")[None, :, None]
+
+    def _c(self):
+        k = np.array([1.0, 2.0, 3.0])
+        dim = self.dim
+        kD = (k[:, None] * k[None, :]) * self.D
+        if self.direction in (EveryDirection, HorizontalDirection):
+            dd = dim if self.direction == EveryDirection else dim - 1
+            s2 = sum(k[i] * k[i] for i in range(dd))
+            skd = 0.0
+            for j in range(dd):
+                for i in range(dd):
+                    skd += kD[i, j]
+            return s2 * skd
+        return k[dim - 1] ** 2 * kD[dim - 1, dim - 1]
+
+    def initial_condition(self, coord, t):
+        k = [1.0, 2.0, 3.0]
+        kx = sum(k[i] * coord[i] for i in range(self.dim))
+        return np.sin(kx) * np.exp(-self._c() * t)
+
+
+class AdvectionDiffusion:
+    """``AdvectionDiffusion{dim}(problem, bcs; num_equations=1, flux_bc, advection,
+    diffusion, hyperdiffusion)`` (advection_diffusion_model.jl:92-123).
+
+    State layout (vars_state, :127-183): prognostic ``rho``; auxiliary
+    ``coord(3) [, u(3)] [, D(9)] [, H(9)]``; gradient ``rho``; gradient-flux
+    ``sigma(3)``; gradient-laplacian ``rho``; hyperdiffusive ``eta(3)``."""
+    physics_id = PHYSICS_ADVECTION_DIFFUSION
+
+    def __init__(self, dim, problem, boundary_conditions=(), flux_bc=False,
+                 advection=True, diffusion=True, hyperdiffusion=False):
+        self.dim = dim
+        self.problem = problem
+        self.boundary_conditions = tuple(boundary_conditions)
+        self.flux_bc = bool(flux_bc)
+        self.advection, self.diffusion, self.hyperdiffusion = (
+            bool(advection), bool(diffusion), bool(hyperdiffusion))
+        o = 3
+        self.off_u = o
+        o += 3 if self.advection else 0
+        self.off_D = o
+        o += 9 if self.diffusion else 0
+        self.off_H = o
+        o += 9 if self.hyperdiffusion else 0
+        self.ns = 1
+        self.naux = o
+        self.ngrad = 1 if (self.diffusion or self.hyperdiffusion) else 0
+        self.ngradflux = 3 if self.diffusion else 0
+        self.ngradlap = 1 if self.hyperdiffusion else 0
+        self.nhyper = 3 if self.hyperdiffusion else 0
+
+    def descriptor(self):
+        ip = np.zeros(16, dtype=np.int32)
+        ip[0] = 1
+        ip[1], ip[2], ip[3] = self.advection, self.diffusion, self.hyperdiffusion
+        ip[4] = self.flux_bc
+        ip[5] = self.problem.problem_id
+        ip[6] = len(self.boundary_conditions)
+        for i, bc in enumerate(self.boundary_conditions):
+            bcs = bc if isinstance(bc, (tuple, list)) else (bc,)
+            m = 0
+            for b in bcs:
+                m |= b.bit
+            ip[7 + i] = m
+        return ip, self.problem.dparam()
+
+    # -- one-time host initialisation (nodal_init_state_auxiliary!, :357-365) --
+    def init_state_auxiliary(self, grid):
+        aux = np.zeros((grid.nelem, self.naux, grid.Np))
+        coord = [grid.vgeo[:, c, :] for c in (_x1, _x2, _x3)]
+        for d in range(3):
+            aux[:, d, :] = coord[d]
+        self.problem.init_velocity_diffusion(self, aux, coord)
+        return aux
+
+    # -- init_state_prognostic! (:384-392) --
+    def init_state_prognostic(self, grid, aux, t):
+        Q = np.zeros((grid.nelem, self.ns, grid.Np))
+        coord = [aux[:, d, :] for d in range(3)]
+        Q[:, 0, :] = self.problem.initial_condition(coord, t)
+        return Q

@@ -20,7 +20,8 @@ def _legendre(N, x):
     p1 = x.copy()
     for n in range(1, N):
         p0, p1 = p1, ((2 * n + 1) * x * p1 - n * p0) / (n + 1)
-    dp = N * (x * p1 - p0) / (x * x - 1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dp = N * (x * p1 - p0) / (x * x - 1)      # unused at x = +-1
     return p1, dp
 
 

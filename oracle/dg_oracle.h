@@ -1,0 +1,134 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C + OpenMP) of the reference's DG kernels, in the
+ * reference's own launch and summation order.  Only tests/, the smoke check in
+ * __graft_entry__.py and bench.py's cpu_baseline leg may build or call this; the
+ * product (climatemachine.jl_amd/, libcmdg.so) never does.
+ *
+ * Pinned against the reference's own golden values (tests/golden/, e.g.
+ * test/Numerics/DGMethods/advection_diffusion/pseudo1D_advection_diffusion.jl:254).
+ *
+ * Array layouts are the reference's column-major ones:
+ *   state (Np, nstate, nelem)      vgeo (Np, nvgeo, nelem)   sgeo (5, Nfp, nface, nelem)
+ *   vmapM/vmapP (Nfp, nface, nelem) int64, 1-based          elemtobndy (nface, nelem) int64
+ *   Grad-type locals are 3 x nvar column-major: g[d + 3*s]   (vars_wrappers.jl:52)
+ */
+#ifndef DG_ORACLE_H
+#define DG_ORACLE_H
+#include <stdint.h>
+
+#define ORC_MAXS 32 /* max vars of any one state type held in a local array */
+
+enum { ORC_EVERY = 0, ORC_HORIZONTAL = 1, ORC_VERTICAL = 2 };
+enum { ORC_NF_RUSANOV = 0, ORC_NF_CENTRAL = 1 };
+/* which numerical flux asks for the boundary state (dispatch of boundary_state!) */
+enum { ORC_BS_FIRST = 0, ORC_BS_GRADIENT = 1 };
+
+typedef struct orc_physics {
+    int ns, naux, ngrad, ngf, ngl, nhyp;
+    int hv_indexmap[ORC_MAXS]; /* hyperdiff_indexmap: ngl entries, 0-based into Gradient vars */
+    int nf_first;              /* ORC_NF_* */
+    const void *p;             /* parameter block of the law */
+    /* pointwise balance-law callbacks (BalanceLaws/interface.jl:37-464) */
+    void (*flux_first_order)(const void *p, double *F, const double *Q, const double *aux,
+                             double t, int dir);
+    void (*flux_second_order)(const void *p, double *F, const double *Q, const double *gf,
+                              const double *hyp, const double *aux, double t);
+    void (*source)(const void *p, double *S, const double *Q, const double *gf,
+                   const double *aux, double t, int dir);
+    void (*gradient_argument)(const void *p, double *G, const double *Q, const double *aux,
+                              double t);
+    void (*gradient_flux)(const void *p, double *gf, const double *gradG, const double *Q,
+                          const double *aux, double t);
+    void (*post_gradient_laplacian)(const void *p, double *hyp, const double *gradlap,
+                                    const double *Q, const double *aux, double t);
+    /* ws has ns entries (a scalar wavespeed is broadcast) */
+    void (*wavespeed)(const void *p, double *ws, const double *n, const double *Q,
+                      const double *aux, double t, int facedir);
+    /* boundary_state! for first-order / gradient numerical fluxes: fills QP, auxP */
+    void (*boundary_state)(const void *p, int kind, int bctag, double *QP, double *auxP,
+                           const double *n, const double *QM, const double *auxM, double t,
+                           const double *Q1, const double *aux1);
+    /* boundary_flux_second_order!: fills F (3 x ns) */
+    void (*boundary_flux_second_order)(const void *p, int bctag, double *F, double *QP,
+                                       double *gfP, double *hypP, double *auxP, const double *n,
+                                       const double *QM, const double *gfM, const double *hypM,
+                                       const double *auxM, double t, const double *Q1,
+                                       const double *gf1, const double *aux1);
+    void (*boundary_state_divergence)(const void *p, int bctag, double *gradP, double *auxP,
+                                      const double *n, const double *gradM, const double *auxM,
+                                      double t);
+    void (*boundary_state_higher_order)(const void *p, int bctag, double *QP, double *auxP,
+                                        double *lapP, const double *n, const double *QM,
+                                        const double *auxM, const double *lapM, double t);
+    /* nodal update_auxiliary_state! hook (NULL: the law's hook returns false) */
+    void (*update_aux)(const void *p, const double *Q, double *aux, double t);
+} orc_physics;
+
+typedef struct orc_grid {
+    int dim;          /* 3 only */
+    int Nq[3];        /* Nq[0] == Nq[1] */
+    int Np, Nfp, nface, nvgeo;
+    int64_t nelem;    /* real + ghost */
+    int64_t nreal;
+    const double *vgeo, *sgeo;
+    const int64_t *vmapM, *vmapP, *elemtobndy;
+    const double *D[3]; /* (Nq, Nq) column-major: D[i + Nq*n] = D_{i n} */
+} orc_grid;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* SpaceDiscretization.jl:1135-1199 -> DGModel_kernels.jl:64-548.  `direction` is the
+ * kernel variant (ORC_HORIZONTAL = the generic kernel called with
+ * HorizontalDirection(), ORC_VERTICAL); model_dir = dg.direction. */
+void orc_volume_tendency(const orc_physics *ph, const orc_grid *g, int model_dir, int direction,
+                         double *tendency, const double *Q, const double *gf, const double *hyp,
+                         const double *aux, double t, double alpha, double beta, int add_source);
+/* DGModel_kernels.jl:588-901; elems: 1-based list */
+void orc_interface_tendency(const orc_physics *ph, const orc_grid *g, int direction,
+                            double *tendency, const double *Q, const double *gf,
+                            const double *hyp, const double *aux, double t, const int64_t *elems,
+                            int64_t nelems, double alpha);
+/* DGModel_kernels.jl:934-1328 */
+void orc_volume_gradients(const orc_physics *ph, const orc_grid *g, int direction,
+                          const double *Q, double *gf, double *hypgrad, const double *aux,
+                          double t, int increment);
+/* DGModel_kernels.jl:1365-1651 */
+void orc_interface_gradients(const orc_physics *ph, const orc_grid *g, int direction,
+                             const double *Q, double *gf, double *hypgrad, const double *aux,
+                             double t, const int64_t *elems, int64_t nelems);
+/* DGModel_kernels.jl:2132-2329 */
+void orc_volume_divergence_of_gradients(const orc_physics *ph, const orc_grid *g, int direction,
+                                        const double *hypgrad, double *hypdiv, int increment);
+/* DGModel_kernels.jl:2360-2494 */
+void orc_interface_divergence_of_gradients(const orc_physics *ph, const orc_grid *g,
+                                           int direction, const double *hypgrad, double *hypdiv,
+                                           const double *aux, double t, const int64_t *elems,
+                                           int64_t nelems);
+/* DGModel_kernels.jl:2525-2824 */
+void orc_volume_gradients_of_laplacians(const orc_physics *ph, const orc_grid *g, int direction,
+                                        double *hypgrad, const double *hypdiv, const double *Q,
+                                        const double *aux, double t, int increment);
+/* DGModel_kernels.jl:2859-3026 */
+void orc_interface_gradients_of_laplacians(const orc_physics *ph, const orc_grid *g,
+                                           int direction, double *hypgrad, const double *hypdiv,
+                                           const double *Q, const double *aux, double t,
+                                           const int64_t *elems, int64_t nelems);
+/* DGModel_kernels.jl:1769-1825; elems = [e0, e1) 0-based range */
+void orc_update_auxiliary_state(const orc_physics *ph, const orc_grid *g, const double *Q,
+                                double *aux, double t, int64_t e0, int64_t e1,
+                                const uint8_t *activedofs);
+/* LowStorageRungeKuttaMethod.jl:146-158 */
+void orc_lsrk_update(double *dQ, double *Q, double rka, double rkb, double dt, int64_t n);
+/* MPIStateArrays.jl:837-871 (pack / unpack of face nodes; vmap 1-based) */
+void orc_fillsendbuf(double *sendbuf, const double *buf, const int64_t *vmapsend, int64_t nvmap,
+                     int Np, int nvar);
+void orc_transferrecvbuf(double *buf, const double *recvbuf, const int64_t *vmaprecv,
+                         int64_t nvmap, int Np, int nvar);
+void orc_set_num_threads(int n);
+int orc_get_max_threads(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

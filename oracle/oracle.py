@@ -1,0 +1,365 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end of ``liboracle.so`` (the C restatement of the reference's DG
+kernels) plus the reference's *orchestration* restated in Python:
+
+* ``OracleDGModel.__call__``  follows ``(dg::DGModel)(tendency, Q, _, t, alpha, beta)``
+  ``src/Numerics/DGMethods/DGModel.jl:85-427`` and the launchers
+  ``SpaceDiscretization.jl:502-1368`` (horizontal kernel then vertical kernel,
+  interior then exterior interface launches, halo begin/end in between);
+* ``lsrk54_step`` / ``solve`` follow ``LowStorageRungeKuttaMethod.jl:102-158,293-327``
+  and ``ODESolvers.jl:49-158``;
+* ``euclidean_distance`` / ``norm`` follow ``MPIStateArrays.jl:583-644`` (mass weighted).
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this module.  Parity pinned by tests/test_oracle_golden.py against the
+reference's stored L2 errors.
+"""
+import ctypes as C
+import os
+import subprocess
+from fractions import Fraction
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EVERY, HORIZONTAL, VERTICAL = 0, 1, 2
+MAXS = 32
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(so) or any(
+            os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+class _Physics(C.Structure):
+    _fields_ = ([(n, C.c_int) for n in ("ns", "naux", "ngrad", "ngf", "ngl", "nhyp")]
+                + [("hv_indexmap", C.c_int * MAXS), ("nf_first", C.c_int), ("p", C.c_void_p)]
+                + [(n, C.c_void_p) for n in (
+                    "flux_first_order", "flux_second_order", "source", "gradient_argument",
+                    "gradient_flux", "post_gradient_laplacian", "wavespeed", "boundary_state",
+                    "boundary_flux_second_order", "boundary_state_divergence",
+                    "boundary_state_higher_order", "update_aux")])
+
+
+class _Grid(C.Structure):
+    _fields_ = [("dim", C.c_int), ("Nq", C.c_int * 3), ("Np", C.c_int), ("Nfp", C.c_int),
+                ("nface", C.c_int), ("nvgeo", C.c_int), ("nelem", C.c_int64),
+                ("nreal", C.c_int64), ("vgeo", C.c_void_p), ("sgeo", C.c_void_p),
+                ("vmapM", C.c_void_p), ("vmapP", C.c_void_p), ("elemtobndy", C.c_void_p),
+                ("D", C.c_void_p * 3)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_advdiff_new.restype = C.POINTER(_Physics)
+        _LIB.orc_advdiff_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        if hasattr(_LIB, "orc_atmos_new"):
+            _LIB.orc_atmos_new.restype = C.POINTER(_Physics)
+            _LIB.orc_atmos_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _LIB.orc_physics_free.argtypes = [C.POINTER(_Physics)]
+        _LIB.orc_get_max_threads.restype = C.c_int
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
+def get_max_threads():
+    return int(lib().orc_get_max_threads())
+
+
+class OracleGrid:
+    """Keeps the numpy tables alive and exposes the C ``orc_grid``."""
+
+    def __init__(self, grid):
+        assert grid.dim == 3, "the oracle restates the 3-D kernels"
+        self.grid = grid
+        self.vgeo = np.ascontiguousarray(grid.vgeo, dtype=np.float64)
+        self.sgeo = np.ascontiguousarray(grid.sgeo, dtype=np.float64)
+        self.vmapM = np.ascontiguousarray(grid.vmapM, dtype=np.int64)
+        self.vmapP = np.ascontiguousarray(grid.vmapP, dtype=np.int64)
+        self.elemtobndy = np.ascontiguousarray(grid.elemtobndy, dtype=np.int64)
+        # reference D is (Nq, Nq) column-major with D[i, n]; numpy C-order => transpose
+        self.D = [np.ascontiguousarray(d.T, dtype=np.float64) for d in grid.D]
+        g = _Grid()
+        g.dim = 3
+        g.Nq[:] = grid.Nq
+        g.Np, g.Nfp, g.nface, g.nvgeo = grid.Np, max(grid.Nfp), 6, self.vgeo.shape[1]
+        g.nelem, g.nreal = grid.nelem, grid.nreal
+        g.vgeo, g.sgeo = _p(self.vgeo), _p(self.sgeo)
+        g.vmapM, g.vmapP, g.elemtobndy = _p(self.vmapM), _p(self.vmapP), _p(self.elemtobndy)
+        for i in range(3):
+            g.D[i] = self.D[i].ctypes.data
+        self.c = g
+        self.interior = np.ascontiguousarray(grid.interiorelems, dtype=np.int64)
+        self.exterior = np.ascontiguousarray(grid.exteriorelems, dtype=np.int64)
+        self.activedofs = np.ascontiguousarray(grid.activedofs, dtype=np.uint8)
+
+
+class OraclePhysics:
+    def __init__(self, law, nf_first=0):
+        ip, dp = law.descriptor()
+        self._ip = np.ascontiguousarray(ip, dtype=np.int32)
+        self._dp = np.ascontiguousarray(dp, dtype=np.float64)
+        ctor = {1: "orc_advdiff_new", 2: "orc_atmos_new"}[law.physics_id]
+        self.c = getattr(lib(), ctor)(_p(self._ip), _p(self._dp), int(nf_first))
+        ph = self.c.contents
+        self.ns, self.naux, self.ngrad = ph.ns, ph.naux, ph.ngrad
+        self.ngf, self.ngl, self.nhyp = ph.ngf, ph.ngl, ph.nhyp
+        assert (self.ns, self.naux, self.ngrad, self.ngf, self.ngl, self.nhyp) == (
+            law.ns, law.naux, law.ngrad, law.ngradflux, law.ngradlap, law.nhyper)
+
+    def __del__(self):
+        try:
+            lib().orc_physics_free(self.c)
+        except Exception:
+            pass
+
+
+class NoExchange:
+    """Single-rank halo: nothing to do."""
+
+    def begin(self, arr, nvar):
+        return None
+
+    def end(self, arr, nvar, token):
+        return None
+
+
+class OracleDGModel:
+    """``DGModel(balance_law, grid, nf_first, nf_second, nf_gradient; direction,
+    diffusion_direction)`` (DGModel.jl:22-65) evaluated with the oracle kernels."""
+
+    def __init__(self, law, grid, nf_first=0, direction=EVERY, diffusion_direction=None,
+                 state_auxiliary=None, exchange=None):
+        self.law = law
+        self.grid = grid
+        self.og = OracleGrid(grid)
+        self.ph = OraclePhysics(law, nf_first)
+        self.direction = direction
+        self.diffusion_direction = direction if diffusion_direction is None else diffusion_direction
+        ne, Np = grid.nelem, grid.Np
+        self.state_auxiliary = (law.init_state_auxiliary(grid) if state_auxiliary is None
+                                else state_auxiliary)
+        self.state_gradient_flux = np.zeros((ne, max(self.ph.ngf, 0), Np))
+        self.Qhypervisc_grad = np.zeros((ne, 3 * self.ph.ngl, Np))
+        self.Qhypervisc_div = np.zeros((ne, self.ph.nhyp, Np))
+        self.exchange = exchange or NoExchange()
+        self.L = lib()
+
+    # -- launchers (SpaceDiscretization.jl) ----------------------------------
+    def _dirs(self, d):
+        return (d in (EVERY, HORIZONTAL)), (d in (EVERY, VERTICAL))
+
+    def _elems(self, surface):
+        return self.og.interior if surface == "interior" else self.og.exterior
+
+    def launch_volume_gradients(self, Q, t):
+        h, v = self._dirs(self.diffusion_direction)
+        a = (self.ph.c, C.byref(self.og.c))
+        if h:
+            self.L.orc_volume_gradients(*a, HORIZONTAL, _p(Q), _p(self.state_gradient_flux),
+                                        _p(self.Qhypervisc_grad), _p(self.state_auxiliary),
+                                        C.c_double(t), 0)
+        if v:
+            self.L.orc_volume_gradients(*a, VERTICAL, _p(Q), _p(self.state_gradient_flux),
+                                        _p(self.Qhypervisc_grad), _p(self.state_auxiliary),
+                                        C.c_double(t),
+                                        int(self.diffusion_direction != VERTICAL))
+
+    def launch_interface_gradients(self, Q, t, surface):
+        h, v = self._dirs(self.diffusion_direction)
+        el = self._elems(surface)
+        for on, d in ((h, HORIZONTAL), (v, VERTICAL)):
+            if on:
+                self.L.orc_interface_gradients(
+                    self.ph.c, C.byref(self.og.c), d, _p(Q), _p(self.state_gradient_flux),
+                    _p(self.Qhypervisc_grad), _p(self.state_auxiliary), C.c_double(t),
+                    _p(el), C.c_int64(len(el)))
+
+    def launch_volume_divergence_of_gradients(self):
+        h, v = self._dirs(self.diffusion_direction)
+        if h:
+            self.L.orc_volume_divergence_of_gradients(
+                self.ph.c, C.byref(self.og.c), HORIZONTAL, _p(self.Qhypervisc_grad),
+                _p(self.Qhypervisc_div), 0)
+        if v:
+            self.L.orc_volume_divergence_of_gradients(
+                self.ph.c, C.byref(self.og.c), VERTICAL, _p(self.Qhypervisc_grad),
+                _p(self.Qhypervisc_div), int(self.diffusion_direction != VERTICAL))
+
+    def launch_interface_divergence_of_gradients(self, t, surface):
+        h, v = self._dirs(self.diffusion_direction)
+        el = self._elems(surface)
+        for on, d in ((h, HORIZONTAL), (v, VERTICAL)):
+            if on:
+                self.L.orc_interface_divergence_of_gradients(
+                    self.ph.c, C.byref(self.og.c), d, _p(self.Qhypervisc_grad),
+                    _p(self.Qhypervisc_div), _p(self.state_auxiliary), C.c_double(t),
+                    _p(el), C.c_int64(len(el)))
+
+    def launch_volume_gradients_of_laplacians(self, Q, t):
+        h, v = self._dirs(self.diffusion_direction)
+        if h:
+            self.L.orc_volume_gradients_of_laplacians(
+                self.ph.c, C.byref(self.og.c), HORIZONTAL, _p(self.Qhypervisc_grad),
+                _p(self.Qhypervisc_div), _p(Q), _p(self.state_auxiliary), C.c_double(t), 0)
+        if v:
+            self.L.orc_volume_gradients_of_laplacians(
+                self.ph.c, C.byref(self.og.c), VERTICAL, _p(self.Qhypervisc_grad),
+                _p(self.Qhypervisc_div), _p(Q), _p(self.state_auxiliary), C.c_double(t),
+                int(self.diffusion_direction != VERTICAL))
+
+    def launch_interface_gradients_of_laplacians(self, Q, t, surface):
+        h, v = self._dirs(self.diffusion_direction)
+        el = self._elems(surface)
+        for on, d in ((h, HORIZONTAL), (v, VERTICAL)):
+            if on:
+                self.L.orc_interface_gradients_of_laplacians(
+                    self.ph.c, C.byref(self.og.c), d, _p(self.Qhypervisc_grad),
+                    _p(self.Qhypervisc_div), _p(Q), _p(self.state_auxiliary), C.c_double(t),
+                    _p(el), C.c_int64(len(el)))
+
+    def launch_volume_tendency(self, tendency, Q, t, alpha, beta):
+        h, v = self._dirs(self.direction)
+        a = (self.ph.c, C.byref(self.og.c), self.direction)
+        b = (_p(tendency), _p(Q), _p(self.state_gradient_flux), _p(self.Qhypervisc_grad),
+             _p(self.state_auxiliary), C.c_double(t), C.c_double(alpha))
+        if h:
+            self.L.orc_volume_tendency(*a, HORIZONTAL, *b, C.c_double(beta),
+                                       int(self.direction == HORIZONTAL))
+        if v:
+            self.L.orc_volume_tendency(*a, VERTICAL, *b,
+                                       C.c_double(1.0 if self.direction == EVERY else beta), 1)
+
+    def launch_interface_tendency(self, tendency, Q, t, alpha, surface):
+        h, v = self._dirs(self.direction)
+        el = self._elems(surface)
+        for on, d in ((h, HORIZONTAL), (v, VERTICAL)):
+            if on:
+                self.L.orc_interface_tendency(
+                    self.ph.c, C.byref(self.og.c), d, _p(tendency), _p(Q),
+                    _p(self.state_gradient_flux), _p(self.Qhypervisc_grad),
+                    _p(self.state_auxiliary), C.c_double(t), _p(el), C.c_int64(len(el)),
+                    C.c_double(alpha))
+
+    def update_auxiliary_state(self, Q, t, which):
+        g = self.grid
+        e0, e1 = (0, g.nreal) if which == "real" else (g.nreal, g.nelem)
+        self.L.orc_update_auxiliary_state(self.ph.c, C.byref(self.og.c), _p(Q),
+                                          _p(self.state_auxiliary), C.c_double(t),
+                                          C.c_int64(e0), C.c_int64(e1), _p(self.og.activedofs))
+
+    # -- (dg::DGModel)(tendency, Q, _, t, alpha, beta)   DGModel.jl:85-427 ---------
+    def __call__(self, tendency, Q, t, alpha=1.0, beta=0.0):
+        ph, ex = self.ph, self.exchange
+        topo = self.grid.topology
+        communicate = not (topo.isstacked and self.direction == VERTICAL)
+        self.update_auxiliary_state(Q, t, "real")
+        tok_Q = tok_gf = tok_hg = tok_hd = None
+        if communicate:
+            tok_Q = ex.begin(Q, ph.ns)
+        if ph.ngf > 0 or ph.nhyp > 0:
+            self.launch_volume_gradients(Q, t)
+            self.launch_interface_gradients(Q, t, "interior")
+            if communicate:
+                ex.end(Q, ph.ns, tok_Q)
+                self.update_auxiliary_state(Q, t, "ghost")
+            self.launch_interface_gradients(Q, t, "exterior")
+            if communicate:
+                if ph.ngf > 0:
+                    tok_gf = ex.begin(self.state_gradient_flux, ph.ngf)
+                if ph.nhyp > 0:
+                    tok_hg = ex.begin(self.Qhypervisc_grad, 3 * ph.ngl)
+        if ph.nhyp > 0:
+            self.launch_volume_divergence_of_gradients()
+            self.launch_interface_divergence_of_gradients(t, "interior")
+            if communicate:
+                ex.end(self.Qhypervisc_grad, 3 * ph.ngl, tok_hg)
+            self.launch_interface_divergence_of_gradients(t, "exterior")
+            if communicate:
+                tok_hd = ex.begin(self.Qhypervisc_div, ph.nhyp)
+            self.launch_volume_gradients_of_laplacians(Q, t)
+            self.launch_interface_gradients_of_laplacians(Q, t, "interior")
+            if communicate:
+                ex.end(self.Qhypervisc_div, ph.nhyp, tok_hd)
+            self.launch_interface_gradients_of_laplacians(Q, t, "exterior")
+            if communicate:
+                tok_hg = ex.begin(self.Qhypervisc_grad, 3 * ph.ngl)
+        self.launch_volume_tendency(tendency, Q, t, alpha, beta)
+        self.launch_interface_tendency(tendency, Q, t, alpha, "interior")
+        if communicate:
+            if ph.ngf > 0 or ph.nhyp > 0:
+                if ph.ngf > 0:
+                    ex.end(self.state_gradient_flux, ph.ngf, tok_gf)
+                if ph.nhyp > 0:
+                    ex.end(self.Qhypervisc_grad, 3 * ph.ngl, tok_hg)
+            else:
+                ex.end(Q, ph.ns, tok_Q)
+                self.update_auxiliary_state(Q, t, "ghost")
+        self.launch_interface_tendency(tendency, Q, t, alpha, "exterior")
+
+
+# ---- LSRK54 Carpenter-Kennedy (LowStorageRungeKuttaMethod.jl:293-327) -------------
+def _f(num, den):
+    return float(Fraction(num, den))
+
+
+RKA = (0.0, _f(-567301805773, 1357537059087), _f(-2404267990393, 2016746695238),
+       _f(-3550918686646, 2091501179385), _f(-1275806237668, 842570457699))
+RKB = (_f(1432997174477, 9575080441755), _f(5161836677717, 13612068292357),
+       _f(1720146321549, 2090206949498), _f(3134564353537, 4481467310338),
+       _f(2277821191437, 14882151754819))
+RKC = (0.0, _f(1432997174477, 9575080441755), _f(2526269341429, 6820363962896),
+       _f(2006345519317, 3224310063776), _f(2802321613138, 2924317926251))
+
+
+def lsrk54_step(dg, Q, dQ, t, dt):
+    """``dostep!`` (LowStorageRungeKuttaMethod.jl:102-144): ``rhs!(dQ, Q, p, t + c dt,
+    increment = true)`` then ``update!`` on the real elements."""
+    nreal = dg.grid.nreal
+    n = nreal * Q.shape[1] * Q.shape[2]
+    for s in range(5):
+        dg(dQ, Q, t + RKC[s] * dt, 1.0, 1.0)
+        lib().orc_lsrk_update(_p(dQ), _p(Q), C.c_double(RKA[(s + 1) % 5]),
+                              C.c_double(RKB[s]), C.c_double(dt), C.c_int64(n))
+
+
+def solve(dg, Q, dt, timeend, t0=0.0):
+    """``solve!`` with ``adjustfinalstep = true`` (ODESolvers.jl:49-158)."""
+    dQ = np.zeros_like(Q)
+    t = t0
+    nsteps = 0
+    while t < timeend:
+        step = dt
+        final = False
+        if t + step > timeend:
+            step = timeend - t
+            final = True
+        lsrk54_step(dg, Q, dQ, t, step)
+        t = timeend if final else t + step
+        nsteps += 1
+    return t, nsteps
+
+
+def weighted_norm2_local(grid, A, B=None):
+    """Local part of ``norm`` / ``euclidean_distance`` squared: mass-weighted sum over
+    real elements (MPIStateArrays.jl:583-644, weights = vgeo[:, _M, :])."""
+    nreal = grid.nreal
+    M = grid.vgeo[:nreal, 9, :][:, None, :]
+    d = A[:nreal] if B is None else A[:nreal] - B[:nreal]
+    return float(np.sum(M * d * d))
