@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""DG-RHS DOF-update throughput of the MI355X-native hot path.
+
+``python bench.py --gpus N --steps K --warmup W``; for N > 1 launch with
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N``.
+
+One "step" is one LSRK54 time step = 5 fused (gradient pass + tendency/update pass)
+evaluations of the DG right-hand side on the rank's elements.  ``value`` is the whole-job
+DOF-updates/s: nodes x prognostic states x 5 stages x K steps / wall time (max over
+ranks), with every input resident in HBM before the timed region.  Rank 0 prints ONE JSON
+line (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_workload(cm, name, rank, size, ne, args):
+    """Returns (law, grid, direction, dt, description)."""
+    M, BL = cm.mesh, cm.balancelaws
+    if name == "advdiff-brick":
+        # config 1 physics (pseudo1D_advection_diffusion.jl:293-368) on Ne^3 elements;
+        # weak scaling: Ne x Ne columns per rank -> (Ne * sqrt-ish) handled by growing x1
+        nx = ne * size
+        rng = [np.linspace(-1, 1, nx + 1), np.linspace(-1, 1, ne + 1), np.linspace(-1, 1, ne + 1)]
+        topl = M.StackedBrickTopology(rng, boundary=((1, 2),) * 3, periodicity=(False,) * 3,
+                                      connectivity="full", rank=rank, size=size)
+        grid = M.DiscontinuousSpectralElementGrid(topl, 4)
+        n = np.ones(3) / np.sqrt(3)
+        law = BL.AdvectionDiffusion(3, BL.Pseudo1D(n, 1.0, 1 / 100, -1 / 2, 1 / 10),
+                                    (BL.InhomogeneousBC(0), BL.InhomogeneousBC(1)))
+        dt = (1.0 / 4) / (max(nx, ne) * 16)
+        desc = {"workload": "advection-diffusion Pseudo1D (BASELINE configs[0] physics), N=4, "
+                            "%dx%dx%d brick elements, LSRK54, fp64" % (nx, ne, ne),
+                "elements": nx * ne * ne, "nodes_per_element": 125, "states": law.ns,
+                "parallelism": "element partition (Hilbert), %d rank(s)" % size}
+        return law, grid, 0, dt, desc
+    raise SystemExit("unknown workload %s" % name)
+
+
+def algorithmic_bytes_per_node(law, kernel):
+    """every distinct array element a pass needs moves once;
+    face tables add F = (5*8 + 2*8) * 6 * Nfp / Np = 67 B per node at N = 4."""
+    b, F = 8, 67
+    ns, naux, ngf, ngl, nhyp = law.ns, law.naux, law.ngradflux, law.ngradlap, law.nhyper
+    if kernel == "GRADIENTS":
+        return b * (ns + naux + 9 + ngf + 3 * ngl) + F
+    if kernel == "DIVGRAD":
+        return b * (3 * ngl + 11 + ngl) + F
+    if kernel == "GRADLAP":
+        return b * (ngl + ns + naux + 9 + nhyp) + F
+    if kernel == "TENDENCY":   # + fused LSRK: dQ read/write, Q write
+        return b * (ns + naux + ngf + nhyp + 11 + 2 * ns + ns) + F
+    raise KeyError(kernel)
+
+
+def cpu_baseline(law, grid, direction, dt, budget_s):
+    """The oracle (CPU restatement of the reference kernels in the reference's unfused
+    launch order) timed on this host's cores on the same workload."""
+    from oracle import oracle as O
+    O.build()
+    cores = O.get_max_threads()
+    dg = O.OracleDGModel(law, grid, nf_first=0, direction=direction)
+    Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
+    dQ = np.zeros_like(Q)
+    O.lsrk54_step(dg, Q, dQ, 0.0, dt)           # warm-up (page faults, thread pool)
+    n, t0 = 0, time.time()
+    while True:
+        O.lsrk54_step(dg, Q, dQ, n * dt, dt)
+        n += 1
+        el = time.time() - t0
+        if el > budget_s or n >= 50:
+            break
+    dofs = grid.nreal * grid.Np * law.ns * 5 * n
+    return {"value": dofs / el, "unit": "DOF-updates/s", "cores": cores, "kind": "port",
+            "sample": "%d LSRK54 step(s) of the same workload (%d elements) in %.1f s, "
+                      "OpenMP over elements" % (n, grid.nreal, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="advdiff-brick")
+    ap.add_argument("--ne", type=int, default=32, help="elements per side per rank")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from cmdg_loader import cm
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device(dev))
+
+    t0 = time.time()
+    law, grid, direction, dt, desc = build_workload(cm, args.workload, rank, world, args.ne, args)
+    log("[rank %d] mesh+grid: %d real + %d ghost elements in %.1f s" % (
+        rank, grid.nreal, grid.nelem - grid.nreal, time.time() - t0))
+    dg = cm.dgmodel.DGModel(law, grid, direction=direction, device=dev)
+    if world > 1:
+        import ctypes as C
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            cm._lib.check(cm._lib.lib().cmdg_comm_unique_id(C.cast(buf, C.c_void_p)))
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        uid = uid.to(dev)
+        dist.broadcast(uid, 0)
+        raw = bytes(uid.cpu().numpy().tobytes())
+        cm._lib.check(cm._lib.lib().cmdg_comm_init_rccl(dg.handle, raw, rank, world), dg.handle)
+    Q = dg.init_ode_state(0.0)
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+
+    def sync_all():
+        dg.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    solver.dostep(Q, nsteps=args.warmup)
+    sync_all()
+    dg.profile_reset()
+    dg.profile_enable(True)          # HIP events on the launch stream around every kernel
+    sync_all()
+    t0 = time.perf_counter()
+    solver.t = args.warmup * dt
+    solver.dostep(Q, nsteps=args.steps)
+    dg.synchronize()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+        nn = torch.tensor([grid.nreal], device=dev, dtype=torch.int64)
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        total_elems = int(nn.item())
+    else:
+        total_elems = grid.nreal
+    dg.profile_enable(False)
+    finite = bool(torch.isfinite(Q[:grid.nreal]).all().item())
+
+    if rank == 0:
+        dofs = total_elems * grid.Np * law.ns * 5 * args.steps
+        kern = {}
+        for k in ("GRADIENTS", "DIVGRAD", "GRADLAP", "TENDENCY", "PACK", "UNPACK"):
+            ms, n = dg.profile_get(k)
+            if n:
+                kern[k] = (ms / n, n)
+        dom = max((k for k in kern if k in ("GRADIENTS", "DIVGRAD", "GRADLAP", "TENDENCY")),
+                  key=lambda k: kern[k][0] * kern[k][1])
+        avg_ms, nl = kern[dom]
+        elems_per_launch = grid.nreal * 5 * args.steps / nl   # interior/exterior launches split
+        bytes_per_launch = algorithmic_bytes_per_node(law, dom) * grid.Np * elems_per_launch
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "DG RHS DOF-updates/sec", "value": dofs / el, "unit": "DOF-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": desc,
+            "node_updates_per_s": dofs / el / law.ns,
+            "state_finite": finite,
+            "kernels_ms": {k: {"avg_ms": v[0], "launches": v[1]} for k, v in kern.items()},
+            "roofline": {"bound": "hbm", "kernel": "k_%s" % dom.lower(), "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "algorithmic_bytes_per_node": algorithmic_bytes_per_node(law, dom),
+                         "avg_launch_ms": avg_ms},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(law, grid, direction, dt, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    dg.close()
+
+
+if __name__ == "__main__":
+    main()

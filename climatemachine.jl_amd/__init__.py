@@ -1,6 +1,17 @@
 """cmdg-mi355x: MI355X-native DG right-hand side + explicit LSRK time stepping for
 ClimateMachine-style balance laws.  Import through
-``cmdg_loader`` (alias ``climatemachine_jl_amd``)."""
-from . import mesh  # noqa: F401
+``cmdg_loader`` (alias ``climatemachine_jl_amd``).
 
-__all__ = ["mesh"]
+``mesh`` and ``balancelaws`` are host-only (numpy).  ``dgmodel`` / ``odesolvers``
+need torch (device memory) and ``libcmdg.so`` (the hand-written HIP kernels); they
+are imported lazily so that the host-side pieces work without a GPU."""
+from . import balancelaws, mesh  # noqa: F401
+
+__all__ = ["mesh", "balancelaws", "dgmodel", "odesolvers"]
+
+
+def __getattr__(name):
+    if name in ("dgmodel", "odesolvers", "_lib"):
+        import importlib
+        return importlib.import_module("." + name, __name__)
+    raise AttributeError(name)

@@ -1,0 +1,98 @@
+"""ctypes binding of ``libcmdg.so`` (the C ABI of ``include/cmdg.h``).
+
+The product path has no CPU fallback: if the HIP library is missing or does not
+export a declared symbol this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcmdg.so")
+
+CMDG_K = dict(GRADIENTS=0, DIVGRAD=1, GRADLAP=2, TENDENCY=3, PACK=4, UNPACK=5, UPDATE_AUX=6)
+
+
+class CmdgDesc(C.Structure):
+    """``cmdg_desc`` of include/cmdg.h."""
+    _fields_ = [
+        ("dim", C.c_int32), ("N", C.c_int32 * 3),
+        ("nreal", C.c_int64), ("nghost", C.c_int64),
+        ("nvgeo", C.c_int32), ("physics_id", C.c_int32),
+        ("iparam", C.c_int32 * 16), ("dparam", C.c_double * 32),
+        ("nf_first", C.c_int32), ("direction", C.c_int32),
+        ("diffusion_direction", C.c_int32), ("stacked", C.c_int32),
+        ("vgeo", C.c_void_p), ("sgeo", C.c_void_p),
+        ("vmapM", C.c_void_p), ("vmapP", C.c_void_p), ("elemtobndy", C.c_void_p),
+        ("interiorelems", C.c_void_p), ("ninterior", C.c_int64),
+        ("exteriorelems", C.c_void_p), ("nexterior", C.c_int64),
+        ("activedofs", C.c_void_p), ("D", C.c_void_p),
+        ("vmapsend", C.c_void_p), ("nvmapsend", C.c_int64),
+        ("vmaprecv", C.c_void_p), ("nvmaprecv", C.c_int64),
+        ("nnabr", C.c_int32), ("nabrtorank", C.c_void_p),
+        ("nabrtovmapsend", C.c_void_p), ("nabrtovmaprecv", C.c_void_p),
+        ("state_auxiliary", C.c_void_p), ("state_gradient_flux", C.c_void_p),
+        ("Qhypervisc_grad", C.c_void_p), ("Qhypervisc_div", C.c_void_p),
+    ]
+
+
+# every symbol include/cmdg.h declares: (name, restype, argtypes)
+_vp, _i32, _i64, _d = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+SYMBOLS = [
+    ("cmdg_version", C.c_char_p, []),
+    ("cmdg_status_string", C.c_char_p, [C.c_int]),
+    ("cmdg_physics_counts", C.c_int, [_i32, _vp, _vp]),
+    ("cmdg_create", C.c_int, [C.POINTER(CmdgDesc), C.POINTER(_vp)]),
+    ("cmdg_destroy", C.c_int, [_vp]),
+    ("cmdg_last_error", C.c_char_p, [_vp]),
+    ("cmdg_rhs", C.c_int, [_vp, _vp, _vp, _d, _d, _d]),
+    ("cmdg_rhs_async", C.c_int, [_vp, _vp, _vp, _d, _d, _d]),
+    ("cmdg_lsrk_step", C.c_int, [_vp, _vp, _vp, _d, _d, _i32, _vp, _vp, _vp]),
+    ("cmdg_lsrk_run", C.c_int, [_vp, _vp, _vp, _d, _d, _i64, _i32, _vp, _vp, _vp]),
+    ("cmdg_synchronize", C.c_int, [_vp]),
+    ("cmdg_halo_begin", C.c_int, [_vp, _vp, _i32]),
+    ("cmdg_halo_end", C.c_int, [_vp, _vp, _i32]),
+    ("cmdg_comm_unique_id", C.c_int, [_vp]),
+    ("cmdg_comm_init_rccl", C.c_int, [_vp, _vp, _i32, _i32]),
+    ("cmdg_comm_connect_local", C.c_int, [_vp, _i32]),
+    ("cmdg_group_rhs", C.c_int, [_vp, _i32, _vp, _vp, _d, _d, _d]),
+    ("cmdg_group_lsrk_run", C.c_int, [_vp, _i32, _vp, _vp, _d, _d, _i64, _i32, _vp, _vp, _vp]),
+    ("cmdg_norm2_local", C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    ("cmdg_distance2_local", C.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    ("cmdg_profile_enable", C.c_int, [_vp, _i32]),
+    ("cmdg_profile_get", C.c_int, [_vp, _i32, _vp, _vp]),
+    ("cmdg_profile_reset", C.c_int, [_vp]),
+]
+
+_LIB = None
+
+
+class CmdgError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load ``libcmdg.so`` (after torch, so that both use one HIP runtime)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise CmdgError(
+                "libcmdg.so is not built (%s); run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` -- there is no CPU fallback" % LIB_PATH)
+        try:
+            import torch  # noqa: F401  (loads libamdhip64 / librccl first)
+        except Exception:
+            pass
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            f = getattr(L, name)          # AttributeError if a declared symbol is missing
+            f.restype = res
+            f.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(status, handle=None):
+    if status != 0:
+        L = lib()
+        msg = L.cmdg_last_error(handle).decode() if True else ""
+        raise CmdgError("libcmdg: %s (%d): %s" % (
+            L.cmdg_status_string(status).decode(), status, msg))

@@ -25,7 +25,7 @@ __all__ = [
     "EveryDirection", "HorizontalDirection", "VerticalDirection",
     "RusanovNumericalFlux", "CentralNumericalFluxFirstOrder",
     "InhomogeneousBC", "HomogeneousBC", "AdvectionDiffusion", "Pseudo1D",
-    "ConstantHyperDiffusion",
+    "ConstantHyperDiffusion", "DirectionSplitBox",
 ]
 
 
@@ -115,6 +115,35 @@ class ConstantHyperDiffusion:
         k = [1.0, 2.0, 3.0]
         kx = sum(k[i] * coord[i] for i in range(self.dim))
         return np.sin(kx) * np.exp(-self._c() * t)
+
+
+class DirectionSplitBox:
+    """``TestProblem{adv, diff, dir, Box}`` of the reference's tendency-splitting test
+    (direction_splitting_advection_diffusion.jl:28-68): u = P sin(pi x), D = P / 200,
+    rho0 = prod(sin(pi x)), with P the projection selected by ``dir`` (k = e_3)."""
+    problem_id = 4
+
+    def __init__(self, direction, advection=True, diffusion=True):
+        self.direction, self.adv, self.diff = direction, advection, diffusion
+        k = np.array([0.0, 0.0, 1.0])
+        kk = np.outer(k, k)
+        self.P = {EveryDirection: np.eye(3), VerticalDirection: kk,
+                  HorizontalDirection: np.eye(3) - kk}[direction]
+
+    def dparam(self):
+        return np.zeros(32)
+
+    def init_velocity_diffusion(self, law, aux, coord):
+        x = np.stack(coord, axis=1)                      # (nelem, 3, Np)
+        if law.advection:
+            u = np.einsum("ij,ejn->ein", self.P, np.sin(np.pi * x)) if self.adv else 0 * x
+            aux[:, law.off_u:law.off_u + 3, :] = u
+        if law.diffusion:
+            D = self.P / 200 if self.diff else np.zeros((3, 3))
+            aux[:, law.off_D:law.off_D + 9, :] = D.flatten(order="F")[None, :, None]
+
+    def initial_condition(self, coord, t):
+        return np.sin(np.pi * coord[0]) * np.sin(np.pi * coord[1]) * np.sin(np.pi * coord[2])
 
 
 class AdvectionDiffusion:

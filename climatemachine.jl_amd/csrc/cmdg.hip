@@ -1,0 +1,742 @@
+// libcmdg: engine orchestration + the C ABI declared in include/cmdg.h.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "engine.h"
+
+namespace cmdg {
+
+#define HIPCHK(call)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(CMDG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- RCCL, resolved lazily so that single-GPU use has no link-time dependency -------
+namespace rccl {
+typedef struct { char internal[128]; } uid_t;
+typedef int (*GetUniqueId_t)(uid_t *);
+typedef int (*CommInitRank_t)(void **, int, uid_t, int);
+typedef int (*CommDestroy_t)(void *);
+typedef int (*GroupStart_t)();
+typedef int (*GroupEnd_t)();
+typedef int (*Send_t)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*Recv_t)(void *, size_t, int, int, void *, hipStream_t);
+typedef const char *(*GetErrorString_t)(int);
+static void *lib = nullptr;
+static GetUniqueId_t GetUniqueId;
+static CommInitRank_t CommInitRank;
+static CommDestroy_t CommDestroy;
+static GroupStart_t GroupStart;
+static GroupEnd_t GroupEnd;
+static Send_t Send;
+static Recv_t Recv;
+static GetErrorString_t GetErrorString;
+constexpr int kDouble = 8;  // ncclFloat64 / ncclDouble
+static bool load(std::string &err)
+{
+    if (lib) return true;
+    const char *names[] = {"librccl.so.1", "librccl.so", nullptr};
+    for (int i = 0; names[i] && !lib; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+        err = std::string("cannot load librccl: ") + dlerror();
+        return false;
+    }
+#define SYM(n)                                                \
+    n = (n##_t)dlsym(lib, "nccl" #n);                         \
+    if (!n) {                                                 \
+        err = "librccl lacks nccl" #n;                        \
+        return false;                                         \
+    }
+    SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(GroupStart) SYM(GroupEnd) SYM(Send)
+        SYM(Recv) SYM(GetErrorString)
+#undef SYM
+    return true;
+}
+}  // namespace rccl
+
+// ---------------------------------------------------------------------------------
+EngineBase::~EngineBase()
+{
+    if (s_comp) hipStreamSynchronize(s_comp);
+    if (s_comm) hipStreamSynchronize(s_comm);
+    prof_collect();
+    for (auto &s : slot) {
+        if (s.sendbuf) hipFree(s.sendbuf);
+        if (s.recvbuf) hipFree(s.recvbuf);
+        if (s.ev_packed) hipEventDestroy(s.ev_packed);
+        if (s.ev_done) hipEventDestroy(s.ev_done);
+        if (s.ev_pulled) hipEventDestroy(s.ev_pulled);
+    }
+    if (own_gf && gf) hipFree(gf);
+    if (own_hg && hypgrad) hipFree(hypgrad);
+    if (own_hd && hypdiv) hipFree(hypdiv);
+    if (W[0]) hipFree(W[0]);
+    if (W[1]) hipFree(W[1]);
+    if (d_D) hipFree(d_D);
+    if (d_partial) hipFree(d_partial);
+    if (ev_comp) hipEventDestroy(ev_comp);
+    if (nccl_comm && rccl::CommDestroy) rccl::CommDestroy(nccl_comm);
+    if (s_comp) hipStreamDestroy(s_comp);
+    if (s_comm) hipStreamDestroy(s_comm);
+}
+
+int EngineBase::init(const cmdg_desc *d)
+{
+    Np = NQ * NQ * NQ;
+    Nfp = NQ * NQ;
+    nreal = d->nreal;
+    nghost = d->nghost;
+    nelem = nreal + nghost;
+    nf_first = d->nf_first;
+    direction = d->direction;
+    diffusion_direction = d->diffusion_direction;
+    stacked = d->stacked;
+    if (!d->vgeo || !d->sgeo || !d->vmapM || !d->vmapP || !d->elemtobndy || !d->D ||
+        !d->state_auxiliary)
+        return fail(CMDG_ERR_INVALID, "cmdg_create: a required grid/state pointer is NULL");
+    if (d->nvgeo < 11) return fail(CMDG_ERR_INVALID, "cmdg_create: vgeo needs >= 11 columns");
+    if (d->ninterior + d->nexterior != nreal)
+        return fail(CMDG_ERR_INVALID, "cmdg_create: interior + exterior != nreal");
+    if ((d->ninterior > 0 && !d->interiorelems) || (d->nexterior > 0 && !d->exteriorelems))
+        return fail(CMDG_ERR_INVALID, "cmdg_create: element list pointer is NULL");
+    if (direction < 0 || direction > 2 || diffusion_direction < 0 || diffusion_direction > 2)
+        return fail(CMDG_ERR_INVALID, "cmdg_create: bad direction");
+    g.vgeo = d->vgeo;
+    g.sgeo = d->sgeo;
+    g.vmapM = d->vmapM;
+    g.vmapP = d->vmapP;
+    g.elemtobndy = d->elemtobndy;
+    g.nvgeo = d->nvgeo;
+    d_interior = d->interiorelems;
+    ninterior = d->ninterior;
+    d_exterior = d->exteriorelems;
+    nexterior = d->nexterior;
+    d_activedofs = d->activedofs;
+    d_vmapsend = d->vmapsend;
+    nvmapsend = d->nvmapsend;
+    d_vmaprecv = d->vmaprecv;
+    nvmaprecv = d->nvmaprecv;
+    if (d->nnabr > 0) {
+        if (!d->nabrtorank || !d->nabrtovmapsend || !d->nabrtovmaprecv || !d->vmapsend ||
+            !d->vmaprecv)
+            return fail(CMDG_ERR_INVALID, "cmdg_create: halo tables missing");
+        nabrtorank.assign(d->nabrtorank, d->nabrtorank + d->nnabr);
+        nabrsend.assign(d->nabrtovmapsend, d->nabrtovmapsend + 2 * d->nnabr);
+        nabrrecv.assign(d->nabrtovmaprecv, d->nabrtovmaprecv + 2 * d->nnabr);
+    }
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&s_comm, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ev_comp, hipEventDisableTiming));
+    HIPCHK(hipMalloc(&d_D, sizeof(double) * NQ * NQ));
+    HIPCHK(hipMemcpy(d_D, d->D, sizeof(double) * NQ * NQ, hipMemcpyHostToDevice));
+    g.D = d_D;
+    aux = d->state_auxiliary;
+    const size_t nd = (size_t)Np * nelem;
+    auto alloc0 = [&](double **p, size_t n) -> int {
+        if (n == 0) n = 1;
+        HIPCHK(hipMalloc(p, sizeof(double) * n));
+        HIPCHK(hipMemset(*p, 0, sizeof(double) * n));
+        return CMDG_OK;
+    };
+    gf = d->state_gradient_flux;
+    if (!gf) {
+        own_gf = true;
+        if (int r = alloc0(&gf, nd * ngf)) return r;
+    }
+    hypgrad = d->Qhypervisc_grad;
+    if (!hypgrad) {
+        own_hg = true;
+        if (int r = alloc0(&hypgrad, nd * 3 * ngl)) return r;
+    }
+    hypdiv = d->Qhypervisc_div;
+    if (!hypdiv) {
+        own_hd = true;
+        if (int r = alloc0(&hypdiv, nd * nhyp)) return r;
+    }
+    slot_nvar_max = std::max(std::max(ns, ngf), std::max(3 * ngl, nhyp));
+    if (communicate()) {
+        for (auto &s : slot) {
+            HIPCHK(hipMalloc(&s.sendbuf, sizeof(double) * slot_nvar_max * std::max<int64_t>(nvmapsend, 1)));
+            HIPCHK(hipMalloc(&s.recvbuf, sizeof(double) * slot_nvar_max * std::max<int64_t>(nvmaprecv, 1)));
+            HIPCHK(hipEventCreateWithFlags(&s.ev_packed, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&s.ev_pulled, hipEventDisableTiming));
+        }
+    }
+    HIPCHK(hipMalloc(&d_partial, sizeof(double) * 1024));
+    return CMDG_OK;
+}
+
+int EngineBase::ensure_work()
+{
+    for (int i = 0; i < 2; ++i)
+        if (!W[i]) {
+            const size_t n = (size_t)Np * ns * nelem;
+            HIPCHK(hipMalloc(&W[i], sizeof(double) * n));
+            HIPCHK(hipMemset(W[i], 0, sizeof(double) * n));
+        }
+    return CMDG_OK;
+}
+
+int EngineBase::synchronize()
+{
+    HIPCHK(hipStreamSynchronize(s_comp));
+    HIPCHK(hipStreamSynchronize(s_comm));
+    return CMDG_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------
+void EngineBase::prof_begin(int kernel, hipStream_t st)
+{
+    if (!profiling) return;
+    ProfRec r;
+    r.kernel = kernel;
+    hipEventCreate(&r.e0);
+    hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, st);
+    prof.push_back(r);
+}
+void EngineBase::prof_end(hipStream_t st)
+{
+    if (!profiling) return;
+    hipEventRecord(prof.back().e1, st);
+}
+void EngineBase::prof_collect()
+{
+    for (auto &r : prof) {
+        hipEventSynchronize(r.e1);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            prof_ms[r.kernel] += ms;
+            prof_n[r.kernel] += 1;
+        }
+        hipEventDestroy(r.e0);
+        hipEventDestroy(r.e1);
+    }
+    prof.clear();
+}
+
+// ---- halo: begin_ghost_exchange! / end_ghost_exchange!  MPIStateArrays.jl:411-483 ----
+int EngineBase::halo_begin(int s, double *array, int nvar)
+{
+    if (!communicate()) return CMDG_OK;
+    if (transport == TRANSPORT_NONE)
+        return fail(CMDG_ERR_COMM, "halo exchange needs cmdg_comm_init_rccl or cmdg_comm_connect_local");
+    HaloSlot &h = slot[s];
+    if (h.active) return fail(CMDG_ERR_INVALID, "The current ghost exchange must end before another begins.");
+    if (nvar > slot_nvar_max) return fail(CMDG_ERR_INVALID, "halo: nstate too large for the buffers");
+    h.active = true;
+    h.nvar = nvar;
+    h.array = array;
+    // the data to send is produced on the compute stream
+    HIPCHK(hipEventRecord(ev_comp, s_comp));
+    HIPCHK(hipStreamWaitEvent(s_comm, ev_comp, 0));
+    if (transport == TRANSPORT_LOCAL) {
+        // neighbours must have pulled the previous payload of this slot
+        for (int r : nabrtorank) HIPCHK(hipStreamWaitEvent(s_comm, group[r]->slot[s].ev_pulled, 0));
+    }
+    if (nvmapsend > 0) {
+        const int64_t n = nvmapsend * nvar;
+        prof_begin(CMDG_K_PACK, s_comm);
+        hipLaunchKernelGGL(k_fillsendbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s_comm,
+                           h.sendbuf, array, d_vmapsend, nvmapsend, Np, nvar);
+        prof_end(s_comm);
+    }
+    HIPCHK(hipEventRecord(h.ev_packed, s_comm));
+    if (transport == TRANSPORT_RCCL) {
+        // one group per exchange: every neighbour pair has its own xGMI link
+        if (rccl::GroupStart()) return fail(CMDG_ERR_COMM, "ncclGroupStart failed");
+        for (size_t n = 0; n < nabrtorank.size(); ++n) {
+            const int64_t r0 = nabrrecv[2 * n] - 1, rn = nabrrecv[2 * n + 1] - r0;
+            const int64_t s0 = nabrsend[2 * n] - 1, sn = nabrsend[2 * n + 1] - s0;
+            int rc = rccl::Recv(h.recvbuf + r0 * nvar, (size_t)(rn * nvar), rccl::kDouble,
+                                nabrtorank[n], nccl_comm, s_comm);
+            if (!rc)
+                rc = rccl::Send(h.sendbuf + s0 * nvar, (size_t)(sn * nvar), rccl::kDouble,
+                                nabrtorank[n], nccl_comm, s_comm);
+            if (rc) {
+                rccl::GroupEnd();
+                return fail(CMDG_ERR_COMM, std::string("ncclSend/Recv: ") + rccl::GetErrorString(rc));
+            }
+        }
+        if (int rc = rccl::GroupEnd())
+            return fail(CMDG_ERR_COMM, std::string("ncclGroupEnd: ") + rccl::GetErrorString(rc));
+    }
+    return CMDG_OK;
+}
+
+int EngineBase::halo_end(int s, double *array, int nvar)
+{
+    if (!communicate()) return CMDG_OK;
+    HaloSlot &h = slot[s];
+    if (!h.active) return fail(CMDG_ERR_INVALID, "A ghost exchange must begin before it ends.");
+    if (h.array != array || h.nvar != nvar)
+        return fail(CMDG_ERR_INVALID, "halo_end does not match the pending halo_begin");
+    h.active = false;
+    if (transport == TRANSPORT_LOCAL) {
+        for (size_t n = 0; n < nabrtorank.size(); ++n) {
+            EngineBase *peer = group[nabrtorank[n]];
+            int m = -1;
+            for (size_t q = 0; q < peer->nabrtorank.size(); ++q)
+                if (peer->nabrtorank[q] == rank) m = (int)q;
+            if (m < 0) return fail(CMDG_ERR_COMM, "local transport: neighbour lists are not symmetric");
+            const int64_t r0 = nabrrecv[2 * n] - 1, rn = nabrrecv[2 * n + 1] - r0;
+            const int64_t s0 = peer->nabrsend[2 * m] - 1, sn = peer->nabrsend[2 * m + 1] - s0;
+            if (rn != sn) return fail(CMDG_ERR_COMM, "local transport: send/recv sizes differ");
+            HIPCHK(hipStreamWaitEvent(s_comm, peer->slot[s].ev_packed, 0));
+            HIPCHK(hipMemcpyAsync(h.recvbuf + r0 * nvar, peer->slot[s].sendbuf + s0 * nvar,
+                                  sizeof(double) * rn * nvar, hipMemcpyDeviceToDevice, s_comm));
+        }
+        HIPCHK(hipEventRecord(h.ev_pulled, s_comm));
+    }
+    if (nvmaprecv > 0) {
+        const int64_t n = nvmaprecv * nvar;
+        prof_begin(CMDG_K_UNPACK, s_comm);
+        hipLaunchKernelGGL(k_transferrecvbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           s_comm, array, h.recvbuf, d_vmaprecv, nvmaprecv, Np, nvar);
+        prof_end(s_comm);
+    }
+    HIPCHK(hipEventRecord(h.ev_done, s_comm));
+    HIPCHK(hipStreamWaitEvent(s_comp, h.ev_done, 0));
+    return CMDG_OK;
+}
+
+// ---- (dg::DGModel)(tendency, Q, _, t, alpha, beta)   DGModel.jl:85-427 -----------------
+// The evaluation is cut into segments at the points where the reference ends a ghost
+// exchange, so that a single host thread can drive several ranks in lock step (local
+// transport).  With fused volume+interface kernels an element list is processed whole:
+// interior elements while the halo is in flight, exterior elements after it arrived.
+int EngineBase::rhs_segment(int seg, const RhsCtx &c)
+{
+    const bool comm = communicate() && !(stacked && direction == DIR_VERTICAL);  // (:104-108)
+    const bool grad = ngf > 0 || nhyp > 0;
+    const bool hyper = nhyp > 0;
+    int r;
+#define TRY(x) \
+    if ((r = (x)) != CMDG_OK) return r
+    switch (seg) {
+    case 0:
+        launch_update_aux(c, 0, nreal);
+        if (comm) TRY(halo_begin(SLOT_Q, c.Qin, ns));
+        if (grad) launch_gradients(c, d_interior, ninterior);
+        break;
+    case 1:
+        if (!grad) break;
+        if (comm) {
+            TRY(halo_end(SLOT_Q, c.Qin, ns));
+            launch_update_aux(c, nreal, nelem);
+        }
+        launch_gradients(c, d_exterior, nexterior);
+        if (comm) {
+            if (ngf > 0) TRY(halo_begin(SLOT_GF, gf, ngf));
+            if (hyper) TRY(halo_begin(SLOT_HG, hypgrad, 3 * ngl));
+        }
+        if (hyper) launch_divgrad(c, d_interior, ninterior);
+        break;
+    case 2:
+        if (!hyper) break;
+        if (comm) TRY(halo_end(SLOT_HG, hypgrad, 3 * ngl));
+        launch_divgrad(c, d_exterior, nexterior);
+        if (comm) TRY(halo_begin(SLOT_HD, hypdiv, nhyp));
+        launch_gradlap(c, d_interior, ninterior);
+        break;
+    case 3:
+        if (hyper) {
+            if (comm) TRY(halo_end(SLOT_HD, hypdiv, nhyp));
+            launch_gradlap(c, d_exterior, nexterior);
+            if (comm) TRY(halo_begin(SLOT_HG, hypgrad, 3 * ngl));
+        }
+        launch_tendency(c, d_interior, ninterior);
+        break;
+    case 4:
+        if (comm) {
+            if (grad) {
+                if (ngf > 0) TRY(halo_end(SLOT_GF, gf, ngf));
+                if (hyper) TRY(halo_end(SLOT_HG, hypgrad, 3 * ngl));
+            } else {
+                TRY(halo_end(SLOT_Q, c.Qin, ns));
+                launch_update_aux(c, nreal, nelem);
+            }
+        }
+        launch_tendency(c, d_exterior, nexterior);
+        break;
+    default: break;
+    }
+#undef TRY
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CMDG_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return CMDG_OK;
+}
+
+int EngineBase::rhs_async(const RhsCtx &c)
+{
+    if (transport == TRANSPORT_LOCAL && communicate())
+        return fail(CMDG_ERR_INVALID, "handles connected locally must be driven by the cmdg_group_* calls");
+    for (int s = 0; s < NSEG; ++s)
+        if (int r = rhs_segment(s, c)) return r;
+    return CMDG_OK;
+}
+
+// dostep!  LowStorageRungeKuttaMethod.jl:102-144.  The state rotates Q -> W0 -> W1 -> ...
+// -> Q so that the fused update never writes the array its neighbours still read.
+static void lsrk_stage_buffers(EngineBase *e, double *Q, int s, int nstages, double **in,
+                               double **out)
+{
+    *in = s == 0 ? Q : e->W[(s - 1) % 2];
+    *out = s == nstages - 1 ? Q : e->W[s % 2];
+}
+
+int EngineBase::lsrk_step(double *Q, double *dQ, double t, double dt, int nstages,
+                          const double *rka, const double *rkb, const double *rkc)
+{
+    std::vector<EngineBase *> one{this};
+    double *Qs[1] = {Q}, *dQs[1] = {dQ};
+    if (transport == TRANSPORT_LOCAL && communicate())
+        return fail(CMDG_ERR_INVALID, "handles connected locally must be driven by the cmdg_group_* calls");
+    return group_lsrk_step(one, Qs, dQs, t, dt, nstages, rka, rkb, rkc);
+}
+
+int group_rhs(std::vector<EngineBase *> &g, std::vector<RhsCtx> &c)
+{
+    for (int s = 0; s < EngineBase::NSEG; ++s)
+        for (size_t i = 0; i < g.size(); ++i)
+            if (int r = g[i]->rhs_segment(s, c[i])) return r;
+    return CMDG_OK;
+}
+
+int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, double t, double dt,
+                    int nstages, const double *rka, const double *rkb, const double *rkc)
+{
+    if (nstages < 1) return g[0]->fail(CMDG_ERR_INVALID, "lsrk: nstages < 1");
+    for (auto *e : g)
+        if (int r = e->ensure_work()) return r;
+    std::vector<RhsCtx> c(g.size());
+    for (int s = 0; s < nstages; ++s) {
+        for (size_t i = 0; i < g.size(); ++i) {
+            RhsCtx &x = c[i];
+            lsrk_stage_buffers(g[i], Q[i], s, nstages, &x.Qin, &x.Qout);
+            if (nstages == 1) x.Qout = g[i]->W[0];
+            x.tendency = dQ[i];
+            x.t = t + rkc[s] * dt;
+            x.alpha = 1.0;  // rhs!(dQ, Q, p, time + RKC[s] * dt, increment = true)
+            x.beta = 1.0;
+            x.lsrk = true;
+            x.rkb_dt = rkb[s] * dt;
+            x.rka_next = rka[(s + 1) % nstages];
+        }
+        if (int r = group_rhs(g, c)) return r;
+    }
+    if (nstages == 1)
+        for (size_t i = 0; i < g.size(); ++i) {
+            EngineBase *e = g[i];
+            if (hipMemcpyAsync(Q[i], e->W[0], sizeof(double) * e->Np * e->ns * e->nreal,
+                               hipMemcpyDeviceToDevice, e->s_comp) != hipSuccess)
+                return e->fail(CMDG_ERR_HIP, "lsrk: copy back failed");
+        }
+    return CMDG_OK;
+}
+
+int EngineBase::wsum2(const double *A, const double *B, int nvar, int weighted, double *out)
+{
+    const int nb = 512;
+    hipLaunchKernelGGL(k_wsum2, dim3(nb), dim3(256), 0, s_comp, A, B, g.vgeo, g.nvgeo, Np, nvar,
+                       nreal, weighted, d_partial);
+    double h[nb];
+    HIPCHK(hipMemcpyAsync(h, d_partial, sizeof(double) * nb, hipMemcpyDeviceToHost, s_comp));
+    HIPCHK(hipStreamSynchronize(s_comp));
+    double acc = 0;
+    for (int i = 0; i < nb; ++i) acc += h[i];
+    *out = acc;
+    return CMDG_OK;
+}
+
+}  // namespace cmdg
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+using namespace cmdg;
+
+struct cmdg_context {
+    EngineBase *eng = nullptr;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int set_err(cmdg_handle h, int code)
+{
+    if (h && h->eng && code != CMDG_OK) h->err = h->eng->err;
+    return code;
+}
+
+extern "C" {
+
+const char *cmdg_version(void) { return "cmdg 0.1 (gfx950)"; }
+
+const char *cmdg_status_string(int status)
+{
+    switch (status) {
+    case CMDG_OK: return "ok";
+    case CMDG_ERR_INVALID: return "invalid argument";
+    case CMDG_ERR_HIP: return "HIP runtime error";
+    case CMDG_ERR_NO_DEVICE: return "no gfx950 device";
+    case CMDG_ERR_COMM: return "communication error";
+    case CMDG_ERR_UNSUPPORTED: return "unsupported physics / polynomial order";
+    default: return "unknown status";
+    }
+}
+
+int cmdg_physics_counts(int32_t physics_id, const int32_t *iparam, int32_t out[6])
+{
+    if (!iparam || !out) return CMDG_ERR_INVALID;
+    switch (physics_id) {
+    case CMDG_PHYSICS_ADVECTION_DIFFUSION: return counts_advdiff(iparam, out);
+    case CMDG_PHYSICS_DRY_ATMOS: return counts_atmos(iparam, out);
+    default: return CMDG_ERR_UNSUPPORTED;
+    }
+}
+
+int cmdg_create(const cmdg_desc *d, cmdg_handle *out)
+{
+    if (!d || !out) return CMDG_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        g_create_err = "no HIP device visible";
+        return CMDG_ERR_NO_DEVICE;
+    }
+    if (d->dim != 3 || d->N[0] != d->N[1] || d->N[1] != d->N[2]) {
+        g_create_err = "only dim == 3 with one polynomial order is compiled in";
+        return CMDG_ERR_UNSUPPORTED;
+    }
+    std::string err;
+    EngineBase *e = nullptr;
+    switch (d->physics_id) {
+    case CMDG_PHYSICS_ADVECTION_DIFFUSION: e = make_engine_advdiff(d, err); break;
+    case CMDG_PHYSICS_DRY_ATMOS: e = make_engine_atmos(d, err); break;
+    default: err = "unknown physics_id"; break;
+    }
+    if (!e) {
+        g_create_err = err;
+        return CMDG_ERR_UNSUPPORTED;
+    }
+    int r = e->init(d);
+    if (r != CMDG_OK) {
+        g_create_err = e->err;
+        delete e;
+        return r;
+    }
+    cmdg_context *c = new (std::nothrow) cmdg_context();
+    if (!c) {
+        delete e;
+        return CMDG_ERR_INVALID;
+    }
+    c->eng = e;
+    *out = c;
+    return CMDG_OK;
+}
+
+int cmdg_destroy(cmdg_handle h)
+{
+    if (!h) return CMDG_ERR_INVALID;
+    delete h->eng;
+    delete h;
+    return CMDG_OK;
+}
+
+const char *cmdg_last_error(cmdg_handle h)
+{
+    if (!h) return g_create_err.c_str();
+    return h->err.c_str();
+}
+
+int cmdg_rhs_async(cmdg_handle h, double *tendency, double *Q, double t, double alpha, double beta)
+{
+    if (!h || !tendency || !Q) return CMDG_ERR_INVALID;
+    RhsCtx c;
+    c.tendency = tendency;
+    c.Qin = Q;
+    c.t = t;
+    c.alpha = alpha;
+    c.beta = beta;
+    return set_err(h, h->eng->rhs_async(c));
+}
+
+int cmdg_rhs(cmdg_handle h, double *tendency, double *Q, double t, double alpha, double beta)
+{
+    int r = cmdg_rhs_async(h, tendency, Q, t, alpha, beta);
+    if (r) return r;
+    return set_err(h, h->eng->synchronize());
+}
+
+int cmdg_lsrk_step(cmdg_handle h, double *Q, double *dQ, double t, double dt, int32_t nstages,
+                   const double *rka, const double *rkb, const double *rkc)
+{
+    if (!h || !Q || !dQ || !rka || !rkb || !rkc) return CMDG_ERR_INVALID;
+    return set_err(h, h->eng->lsrk_step(Q, dQ, t, dt, nstages, rka, rkb, rkc));
+}
+
+int cmdg_lsrk_run(cmdg_handle h, double *Q, double *dQ, double t, double dt, int64_t nsteps,
+                  int32_t nstages, const double *rka, const double *rkb, const double *rkc)
+{
+    if (!h || !Q || !dQ || !rka || !rkb || !rkc) return CMDG_ERR_INVALID;
+    for (int64_t i = 0; i < nsteps; ++i) {
+        int r = h->eng->lsrk_step(Q, dQ, t + i * dt, dt, nstages, rka, rkb, rkc);
+        if (r) return set_err(h, r);
+    }
+    return CMDG_OK;
+}
+
+int cmdg_synchronize(cmdg_handle h)
+{
+    if (!h) return CMDG_ERR_INVALID;
+    return set_err(h, h->eng->synchronize());
+}
+
+int cmdg_halo_begin(cmdg_handle h, double *array, int32_t nstate)
+{
+    if (!h || !array) return CMDG_ERR_INVALID;
+    return set_err(h, h->eng->halo_begin(SLOT_Q, array, nstate));
+}
+int cmdg_halo_end(cmdg_handle h, double *array, int32_t nstate)
+{
+    if (!h || !array) return CMDG_ERR_INVALID;
+    return set_err(h, h->eng->halo_end(SLOT_Q, array, nstate));
+}
+
+int cmdg_comm_unique_id(void *out128)
+{
+    std::string err;
+    if (!out128) return CMDG_ERR_INVALID;
+    if (!rccl::load(err)) {
+        g_create_err = err;
+        return CMDG_ERR_COMM;
+    }
+    rccl::uid_t id;
+    if (rccl::GetUniqueId(&id)) return CMDG_ERR_COMM;
+    memcpy(out128, &id, sizeof(id));
+    return CMDG_OK;
+}
+
+int cmdg_comm_init_rccl(cmdg_handle h, const void *unique_id128, int32_t rank, int32_t nranks)
+{
+    if (!h || !unique_id128 || rank < 0 || rank >= nranks) return CMDG_ERR_INVALID;
+    EngineBase *e = h->eng;
+    if (!rccl::load(e->err)) return set_err(h, CMDG_ERR_COMM);
+    rccl::uid_t id;
+    memcpy(&id, unique_id128, sizeof(id));
+    if (int rc = rccl::CommInitRank(&e->nccl_comm, nranks, id, rank))
+        return set_err(h, e->fail(CMDG_ERR_COMM, std::string("ncclCommInitRank: ") +
+                                                   rccl::GetErrorString(rc)));
+    e->transport = TRANSPORT_RCCL;
+    e->rank = rank;
+    e->nranks = nranks;
+    return CMDG_OK;
+}
+
+int cmdg_comm_connect_local(cmdg_handle *handles, int32_t n)
+{
+    if (!handles || n < 1) return CMDG_ERR_INVALID;
+    std::vector<EngineBase *> g;
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i]) return CMDG_ERR_INVALID;
+        g.push_back(handles[i]->eng);
+    }
+    for (int i = 0; i < n; ++i) {
+        g[i]->group = g;
+        g[i]->rank = i;
+        g[i]->nranks = n;
+        g[i]->transport = TRANSPORT_LOCAL;
+        for (int r : g[i]->nabrtorank)
+            if (r < 0 || r >= n) return set_err(handles[i], g[i]->fail(CMDG_ERR_COMM, "neighbour rank outside the local group"));
+    }
+    return CMDG_OK;
+}
+
+int cmdg_group_rhs(cmdg_handle *handles, int32_t n, double **tendency, double **Q, double t,
+                   double alpha, double beta)
+{
+    if (!handles || n < 1 || !tendency || !Q) return CMDG_ERR_INVALID;
+    std::vector<EngineBase *> g;
+    std::vector<RhsCtx> c(n);
+    for (int i = 0; i < n; ++i) {
+        g.push_back(handles[i]->eng);
+        c[i].tendency = tendency[i];
+        c[i].Qin = Q[i];
+        c[i].t = t;
+        c[i].alpha = alpha;
+        c[i].beta = beta;
+    }
+    int r = group_rhs(g, c);
+    if (r)
+        for (int i = 0; i < n; ++i) set_err(handles[i], r);
+    return r;
+}
+
+int cmdg_group_lsrk_run(cmdg_handle *handles, int32_t n, double **Q, double **dQ, double t,
+                        double dt, int64_t nsteps, int32_t nstages, const double *rka,
+                        const double *rkb, const double *rkc)
+{
+    if (!handles || n < 1 || !Q || !dQ || !rka || !rkb || !rkc) return CMDG_ERR_INVALID;
+    std::vector<EngineBase *> g;
+    for (int i = 0; i < n; ++i) g.push_back(handles[i]->eng);
+    for (int64_t s = 0; s < nsteps; ++s) {
+        int r = group_lsrk_step(g, Q, dQ, t + s * dt, dt, nstages, rka, rkb, rkc);
+        if (r) {
+            for (int i = 0; i < n; ++i) set_err(handles[i], r);
+            return r;
+        }
+    }
+    return CMDG_OK;
+}
+
+int cmdg_norm2_local(cmdg_handle h, const double *A, int32_t nstate, int32_t weighted,
+                     double *out_host)
+{
+    if (!h || !A || !out_host) return CMDG_ERR_INVALID;
+    return set_err(h, h->eng->wsum2(A, nullptr, nstate, weighted, out_host));
+}
+int cmdg_distance2_local(cmdg_handle h, const double *A, const double *B, int32_t nstate,
+                         double *out_host)
+{
+    if (!h || !A || !B || !out_host) return CMDG_ERR_INVALID;
+    return set_err(h, h->eng->wsum2(A, B, nstate, 1, out_host));
+}
+
+int cmdg_profile_enable(cmdg_handle h, int32_t on)
+{
+    if (!h) return CMDG_ERR_INVALID;
+    h->eng->profiling = on != 0;
+    return CMDG_OK;
+}
+int cmdg_profile_get(cmdg_handle h, int32_t kernel, double *total_ms, int64_t *launches)
+{
+    if (!h || kernel < 0 || kernel >= CMDG_K_COUNT) return CMDG_ERR_INVALID;
+    h->eng->synchronize();
+    h->eng->prof_collect();
+    if (total_ms) *total_ms = h->eng->prof_ms[kernel];
+    if (launches) *launches = h->eng->prof_n[kernel];
+    return CMDG_OK;
+}
+int cmdg_profile_reset(cmdg_handle h)
+{
+    if (!h) return CMDG_ERR_INVALID;
+    h->eng->synchronize();
+    h->eng->prof_collect();
+    for (int i = 0; i < CMDG_K_COUNT; ++i) {
+        h->eng->prof_ms[i] = 0;
+        h->eng->prof_n[i] = 0;
+    }
+    return CMDG_OK;
+}
+
+}  // extern "C"

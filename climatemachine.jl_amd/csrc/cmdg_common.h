@@ -1,0 +1,71 @@
+// Shared device-side definitions for libcmdg (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cmdg {
+
+// vgeo column ids, 0-based (reference ids Grids.jl:76-92 minus one)
+enum { XI1X1 = 0, XI2X1, XI3X1, XI1X2, XI2X2, XI3X2, XI1X3, XI2X3, XI3X3, VM, VMI };
+// sgeo row ids (Grids.jl:129-130)
+enum { SN1 = 0, SN2, SN3, SSM, SVMI };
+enum { DIR_EVERY = 0, DIR_HORIZONTAL = 1, DIR_VERTICAL = 2 };
+enum { NF_RUSANOV = 0, NF_CENTRAL = 1 };
+enum { BS_FIRST = 0, BS_GRADIENT = 1 };
+
+constexpr int NXCD = 8;
+
+struct GridDev {
+    const double *vgeo, *sgeo;
+    const int64_t *vmapM, *vmapP, *elemtobndy;
+    const double *D;  // device, (Nq, Nq) column-major
+    int nvgeo;
+};
+
+template <int NQ>
+struct KDims {
+    static constexpr int Np = NQ * NQ * NQ;
+    static constexpr int Nfp = NQ * NQ;
+    static constexpr int NFT = 6 * Nfp;  // face-node tasks per element
+    static constexpr int NT = (((Np > NFT ? Np : NFT) + 63) / 64) * 64;
+};
+
+// Blocks b and b+8 share an XCD (and its L2); hand each XCD a contiguous run of the
+// element list so face neighbours (adjacent in the stacked/Hilbert order) hit one L2.
+__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t G)
+{
+    const int64_t q = G / NXCD, r = G % NXCD;
+    const int64_t x = b % NXCD, y = b / NXCD;
+    return x * q + (x < r ? x : r) + y;
+}
+
+template <int N>
+__device__ __forceinline__ void fill_negzero(double (&a)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = -0.0;
+}
+// zero-length-safe local array (C++ forbids T[0])
+template <int N>
+struct Vec {
+    double v[N > 0 ? N : 1];
+    __device__ __forceinline__ double &operator[](int i) { return v[i]; }
+    __device__ __forceinline__ const double &operator[](int i) const { return v[i]; }
+    __device__ __forceinline__ operator double *() { return v; }
+    __device__ __forceinline__ operator const double *() const { return v; }
+    __device__ __forceinline__ void negzero()
+    {
+#pragma unroll
+        for (int i = 0; i < (N > 0 ? N : 1); ++i) v[i] = -0.0;
+    }
+};
+
+template <int NVAR, int Np>
+__device__ __forceinline__ void load_state(Vec<NVAR> &dst, const double *__restrict__ arr, int ijk,
+                                           int64_t e)
+{
+#pragma unroll
+    for (int s = 0; s < NVAR; ++s) dst[s] = arr[ijk + (int64_t)Np * (s + (int64_t)NVAR * e)];
+}
+
+}  // namespace cmdg

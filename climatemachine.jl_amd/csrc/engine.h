@@ -1,0 +1,215 @@
+// Host-side engine: owns streams, events, halo buffers and work buffers of one handle
+// and enqueues the passes of one right-hand-side evaluation in the order of the
+// reference's `(dg::DGModel)(tendency, Q, _, t, alpha, beta)`
+// (src/Numerics/DGMethods/DGModel.jl:85-427).  The physics/polynomial-order specific
+// kernel launches live in EngineT<P, NQ>.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/cmdg.h"
+#include "kernels.h"
+
+namespace cmdg {
+
+enum { SLOT_Q = 0, SLOT_GF = 1, SLOT_HG = 2, SLOT_HD = 3, NSLOT = 4 };
+enum { TRANSPORT_NONE = 0, TRANSPORT_LOCAL = 1, TRANSPORT_RCCL = 2 };
+
+struct HaloSlot {
+    double *sendbuf = nullptr, *recvbuf = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_done = nullptr, ev_pulled = nullptr;
+    bool active = false;  // begin issued, end pending
+    int nvar = 0;
+    double *array = nullptr;
+};
+
+struct RhsCtx {
+    double *tendency = nullptr;
+    double *Qin = nullptr;   // state read by this evaluation (ghosts refreshed in place)
+    double *Qout = nullptr;  // LSRK: updated state
+    double t = 0, alpha = 1, beta = 0;
+    bool lsrk = false;
+    double rkb_dt = 0, rka_next = 0;
+};
+
+struct ProfRec {
+    int kernel;
+    hipEvent_t e0, e1;
+};
+
+struct EngineBase {
+    // ---- configuration (copied from cmdg_desc) ---------------------------------------
+    int NQ = 0, Np = 0, Nfp = 0;
+    int64_t nreal = 0, nghost = 0, nelem = 0;
+    int ns = 0, naux = 0, ngrad = 0, ngf = 0, ngl = 0, nhyp = 0;
+    int nf_first = 0, direction = 0, diffusion_direction = 0, stacked = 0;
+    GridDev g{};
+    const int64_t *d_interior = nullptr, *d_exterior = nullptr;
+    int64_t ninterior = 0, nexterior = 0;
+    const uint8_t *d_activedofs = nullptr;
+    double *d_D = nullptr;
+    const int64_t *d_vmapsend = nullptr, *d_vmaprecv = nullptr;
+    int64_t nvmapsend = 0, nvmaprecv = 0;
+    std::vector<int> nabrtorank;
+    std::vector<int64_t> nabrsend, nabrrecv;  // 2*nnabr (first,last) 1-based
+    double *aux = nullptr, *gf = nullptr, *hypgrad = nullptr, *hypdiv = nullptr;
+    bool own_gf = false, own_hg = false, own_hd = false;
+    // ---- runtime -----------------------------------------------------------------------
+    hipStream_t s_comp = nullptr, s_comm = nullptr;
+    hipEvent_t ev_comp = nullptr;
+    HaloSlot slot[NSLOT];
+    int slot_nvar_max = 0;
+    double *W[2] = {nullptr, nullptr};  // LSRK work states
+    double *d_partial = nullptr;        // reduction scratch
+    int transport = TRANSPORT_NONE;
+    int rank = 0, nranks = 1;
+    std::vector<EngineBase *> group;    // local transport: engine of every rank
+    void *nccl_comm = nullptr;
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    double prof_ms[CMDG_K_COUNT] = {0};
+    int64_t prof_n[CMDG_K_COUNT] = {0};
+    std::string err;
+
+    virtual ~EngineBase();
+    int init(const cmdg_desc *d);
+    int fail(int code, const std::string &msg)
+    {
+        err = msg;
+        return code;
+    }
+    bool communicate() const { return !nabrtorank.empty(); }
+
+    // physics / order specific launches
+    virtual void launch_gradients(const RhsCtx &c, const int64_t *elems, int64_t n) = 0;
+    virtual void launch_divgrad(const RhsCtx &c, const int64_t *elems, int64_t n) = 0;
+    virtual void launch_gradlap(const RhsCtx &c, const int64_t *elems, int64_t n) = 0;
+    virtual void launch_tendency(const RhsCtx &c, const int64_t *elems, int64_t n) = 0;
+    virtual void launch_update_aux(const RhsCtx &c, int64_t e0, int64_t e1) = 0;
+    virtual bool has_update_aux() const = 0;
+
+    // orchestration
+    static constexpr int NSEG = 5;
+    int rhs_segment(int seg, const RhsCtx &c);
+    int rhs_async(const RhsCtx &c);
+    int lsrk_step(double *Q, double *dQ, double t, double dt, int nstages, const double *rka,
+                  const double *rkb, const double *rkc);
+    int halo_begin(int s, double *array, int nvar);
+    int halo_end(int s, double *array, int nvar);
+    int ensure_work();
+    int synchronize();
+    int wsum2(const double *A, const double *B, int nvar, int weighted, double *out);
+
+    // profiling brackets
+    void prof_begin(int kernel, hipStream_t st);
+    void prof_end(hipStream_t st);
+    void prof_collect();
+};
+
+int group_rhs(std::vector<EngineBase *> &g, std::vector<RhsCtx> &c);
+int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, double t, double dt,
+                    int nstages, const double *rka, const double *rkb, const double *rkc);
+
+// ---------------------------------------------------------------------------------
+template <class P, int NQ_>
+struct EngineT : EngineBase {
+    typename P::Params prm;
+    PassArgs<P> make_args(const RhsCtx &c, const int64_t *elems, int64_t n, int dir) const
+    {
+        PassArgs<P> a;
+        a.prm = prm;
+        a.g = g;
+        a.elems = elems;
+        a.nelems = n;
+        a.Q = c.Qin;
+        a.aux = aux;
+        a.gf = gf;
+        a.hypgrad = hypgrad;
+        a.hypdiv = hypdiv;
+        a.tendency = c.tendency;
+        a.Qout = c.Qout;
+        a.t = c.t;
+        a.alpha = c.alpha;
+        a.beta = c.beta;
+        a.rkb_dt = c.rkb_dt;
+        a.rka_next = c.rka_next;
+        a.direction = dir;
+        a.model_dir = direction;
+        a.nf_first = nf_first;
+        return a;
+    }
+    void launch_gradients(const RhsCtx &c, const int64_t *elems, int64_t n) override
+    {
+        if (n <= 0) return;
+        prof_begin(CMDG_K_GRADIENTS, s_comp);
+        hipLaunchKernelGGL((k_gradients<P, NQ_>), dim3((unsigned)n), dim3(KDims<NQ_>::NT), 0,
+                           s_comp, make_args(c, elems, n, diffusion_direction));
+        prof_end(s_comp);
+    }
+    void launch_divgrad(const RhsCtx &c, const int64_t *elems, int64_t n) override
+    {
+        if (n <= 0) return;
+        prof_begin(CMDG_K_DIVGRAD, s_comp);
+        hipLaunchKernelGGL((k_divgrad<P, NQ_>), dim3((unsigned)n), dim3(KDims<NQ_>::NT), 0, s_comp,
+                           make_args(c, elems, n, diffusion_direction));
+        prof_end(s_comp);
+    }
+    void launch_gradlap(const RhsCtx &c, const int64_t *elems, int64_t n) override
+    {
+        if (n <= 0) return;
+        prof_begin(CMDG_K_GRADLAP, s_comp);
+        hipLaunchKernelGGL((k_gradlap<P, NQ_>), dim3((unsigned)n), dim3(KDims<NQ_>::NT), 0, s_comp,
+                           make_args(c, elems, n, diffusion_direction));
+        prof_end(s_comp);
+    }
+    void launch_tendency(const RhsCtx &c, const int64_t *elems, int64_t n) override
+    {
+        if (n <= 0) return;
+        prof_begin(CMDG_K_TENDENCY, s_comp);
+        if (c.lsrk)
+            hipLaunchKernelGGL((k_tendency<P, NQ_, true>), dim3((unsigned)n),
+                               dim3(KDims<NQ_>::NT), 0, s_comp, make_args(c, elems, n, direction));
+        else
+            hipLaunchKernelGGL((k_tendency<P, NQ_, false>), dim3((unsigned)n),
+                               dim3(KDims<NQ_>::NT), 0, s_comp, make_args(c, elems, n, direction));
+        prof_end(s_comp);
+    }
+    void launch_update_aux(const RhsCtx &c, int64_t e0, int64_t e1) override
+    {
+        if constexpr (P::HAS_UPDATE_AUX) {
+            if (e1 <= e0) return;
+            const int64_t n = (e1 - e0) * KDims<NQ_>::Np;
+            prof_begin(CMDG_K_UPDATE_AUX, s_comp);
+            hipLaunchKernelGGL((k_update_aux<P, NQ_>), dim3((unsigned)((n + 255) / 256)), dim3(256),
+                               0, s_comp, prm, c.Qin, aux, d_activedofs, c.t, e0, e1);
+            prof_end(s_comp);
+        }
+    }
+    bool has_update_aux() const override { return P::HAS_UPDATE_AUX; }
+};
+
+template <class P, int NQ_>
+EngineBase *make_engine(const cmdg_desc *d)
+{
+    auto *e = new EngineT<P, NQ_>();
+    e->NQ = NQ_;
+    e->ns = P::NS;
+    e->naux = P::NAUX;
+    e->ngrad = P::NGRAD;
+    e->ngf = P::NGF;
+    e->ngl = P::NGL;
+    e->nhyp = P::NHYP;
+    P::make_params(e->prm, d->iparam, d->dparam);
+    return e;
+}
+
+// factories implemented per physics family (one translation unit each)
+EngineBase *make_engine_advdiff(const cmdg_desc *d, std::string &err);
+int counts_advdiff(const int32_t *iparam, int32_t out[6]);
+EngineBase *make_engine_atmos(const cmdg_desc *d, std::string &err);
+int counts_atmos(const int32_t *iparam, int32_t out[6]);
+
+}  // namespace cmdg

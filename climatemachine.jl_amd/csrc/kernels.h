@@ -1,0 +1,775 @@
+// Hand-written gfx950 kernels of the DG hot path.  One workgroup per element:
+//   phase 1  thread = volume node: pointwise physics, contravariant fluxes / gradient
+//            arguments staged in LDS;
+//   phase 2  thread = volume node: (N+1)-point contractions with D out of LDS, result
+//            into an LDS accumulator;
+//   phase 3  thread = face node (6 faces x Nfp tasks at once): numerical / boundary
+//            fluxes, lifted into the LDS accumulator one opposite-face pair at a time
+//            (race free, reference order);
+//   phase 4  thread = volume node: one coalesced store per output field (for the
+//            tendency kernel with the LSRK update fused in).
+// Each kernel replaces a *group* of reference kernels (horizontal + vertical volume
+// kernel and the per-direction interface launches) of
+// src/Numerics/DGMethods/DGModel_kernels.jl; the accumulation order of the reference
+// is kept term by term (see DESIGN.md "summation order").
+#pragma once
+#include "cmdg_common.h"
+
+namespace cmdg {
+
+// ---------------------------------------------------------------------------------
+template <class P>
+struct PassArgs {
+    typename P::Params prm;
+    GridDev g;
+    const int64_t *elems;  // 1-based element list (interior or exterior)
+    int64_t nelems;
+    // state arrays
+    const double *Q;
+    const double *aux;
+    double *gf;        // state_gradient_flux (written by gradients, read by tendency)
+    double *hypgrad;   // Qhypervisc_grad
+    double *hypdiv;    // Qhypervisc_div
+    double *tendency;  // tendency (== dQ when the LSRK update is fused)
+    double *Qout;      // LSRK: updated state
+    double t, alpha, beta;
+    double rkb_dt, rka_next;
+    int direction;     // direction of this pass (dg.direction or dg.diffusion_direction)
+    int model_dir;     // dg.direction handed to the pointwise fluxes
+    int nf_first;
+};
+
+struct FacePt {
+    double n[3], sM, vMI;
+    int64_t eP;
+    int vidM, vidP, bctag;
+};
+
+template <int NQ>
+__device__ __forceinline__ void face_setup(const GridDev &g, int64_t e, int f, int n, FacePt &fp)
+{
+    constexpr int Np = KDims<NQ>::Np, Nfp = KDims<NQ>::Nfp;
+    const int64_t o = n + (int64_t)Nfp * (f + 6 * e);
+    const double *sg = g.sgeo + 5 * o;
+    fp.n[0] = sg[SN1];
+    fp.n[1] = sg[SN2];
+    fp.n[2] = sg[SN3];
+    fp.sM = sg[SSM];
+    fp.vMI = sg[SVMI];
+    fp.bctag = (int)g.elemtobndy[f + 6 * e];
+    const int64_t idM = g.vmapM[o], idP = g.vmapP[o];
+    fp.eP = (idP - 1) / Np;
+    fp.vidM = (int)((idM - 1) % Np);
+    fp.vidP = (int)((idP - 1) % Np);
+    if (fp.bctag != 0) {  // DGModel_kernels.jl:686-692
+        fp.eP = e;
+        fp.vidP = fp.vidM;
+    }
+}
+
+// numerical_flux_first_order!  NumericalFluxes.jl:223-285 (Rusanov) / :300-340 (central)
+template <class P>
+__device__ __forceinline__ void nf_first_order(const typename P::Params &prm, int nf,
+                                               Vec<P::NS> &fluxn, const double *n,
+                                               const double *QM, const double *auxM,
+                                               const double *QP, const double *auxP, double t,
+                                               int facedir)
+{
+    constexpr int NS = P::NS;
+    Vec<3 * NS> FM, FP;
+    FM.negzero();
+    P::flux_first_order(prm, FM, QM, auxM, t, facedir);
+    FP.negzero();
+    P::flux_first_order(prm, FP, QP, auxP, t, facedir);
+    const double nh0 = n[0] / 2, nh1 = n[1] / 2, nh2 = n[2] / 2;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        fluxn[s] += (FM[3 * s] + FP[3 * s]) * nh0 + (FM[3 * s + 1] + FP[3 * s + 1]) * nh1 +
+                    (FM[3 * s + 2] + FP[3 * s + 2]) * nh2;
+    if (nf == NF_RUSANOV) {
+        Vec<NS> wM, wP;
+        P::wavespeed(prm, wM, n, QM, auxM, t, facedir);
+        P::wavespeed(prm, wP, n, QP, auxP, t, facedir);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double mw = wM[s] > wP[s] ? wM[s] : wP[s];
+            const double pen = mw * (QM[s] - QP[s]);
+            fluxn[s] += pen / 2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Tendency pass: volume_tendency! (:64-548) + dgsem_interface_tendency! (:588-901),
+// optionally fused with the LSRK update! (LowStorageRungeKuttaMethod.jl:146-158).
+template <class P, int NQ, bool LSRK>
+__global__ void __launch_bounds__(KDims<NQ>::NT) k_tendency(const PassArgs<P> a)
+{
+    using KD = KDims<NQ>;
+    constexpr int Np = KD::Np, Nfp = KD::Nfp, NS = P::NS, NAUX = P::NAUX, NGF = P::NGF,
+                  NHYP = P::NHYP, NHG = 3 * P::NGL;
+    __shared__ double sD[NQ * NQ];
+    __shared__ double sF[3 * NS * Np];  // contravariant flux [d][s][ijk]
+    __shared__ double sT[NS * Np];      // tendency accumulator [s][ijk]
+    const int tid = threadIdx.x;
+    const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
+    if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
+    const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
+    Vec<NS> S;
+    double MI = 0;
+    if (tid < Np) {
+        const double *vg = a.g.vgeo + (int64_t)Np * a.g.nvgeo * e + tid;
+        const double M = vg[VM * Np];
+        MI = vg[VMI * Np];
+        Vec<NS> lQ;
+        Vec<NAUX> laux;
+        Vec<NGF> lgf;
+        Vec<NHYP> lhyp;
+        load_state<NS, Np>(lQ, a.Q, tid, e);
+        load_state<NAUX, Np>(laux, a.aux, tid, e);
+        load_state<NGF, Np>(lgf, a.gf, tid, e);
+#pragma unroll
+        for (int s = 0; s < NHYP; ++s)
+            lhyp[s] = a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)];
+        Vec<3 * NS> F, F2;
+        F.negzero();
+        P::flux_first_order(a.prm, F, lQ, laux, a.t, a.model_dir);
+        F2.negzero();
+        P::flux_second_order(a.prm, F2, lQ, lgf, lhyp, laux, a.t);
+#pragma unroll
+        for (int q = 0; q < 3 * NS; ++q) F[q] += F2[q];
+        if (hz) {
+            const double x11 = vg[XI1X1 * Np], x12 = vg[XI1X2 * Np], x13 = vg[XI1X3 * Np];
+            const double x21 = vg[XI2X1 * Np], x22 = vg[XI2X2 * Np], x23 = vg[XI2X3 * Np];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double F1 = F[3 * s], F2_ = F[3 * s + 1], F3 = F[3 * s + 2];
+                sF[(0 * NS + s) * Np + tid] = M * (x11 * F1 + x12 * F2_ + x13 * F3);
+                sF[(1 * NS + s) * Np + tid] = M * (x21 * F1 + x22 * F2_ + x23 * F3);
+            }
+        }
+        if (vt) {
+            const double x31 = vg[XI3X1 * Np], x32 = vg[XI3X2 * Np], x33 = vg[XI3X3 * Np];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double F1 = F[3 * s], F2_ = F[3 * s + 1], F3 = F[3 * s + 2];
+                sF[(2 * NS + s) * Np + tid] = M * (x31 * F1 + x32 * F2_ + x33 * F3);
+            }
+        }
+        S.negzero();
+        if constexpr (P::HAS_SOURCE) P::source(a.prm, S, lQ, lgf, laux, a.t, a.model_dir);
+    }
+    __syncthreads();
+    if (tid < Np) {
+        const int i = tid % NQ, j = (tid / NQ) % NQ, k = tid / (NQ * NQ);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            double T = 0.0;
+            const double Told =
+                a.beta != 0 ? a.tendency[tid + (int64_t)Np * (s + (int64_t)NS * e)] : 0.0;
+            if (hz) {  // generic kernel called with HorizontalDirection() (:64-309)
+                double lt = 0.0;
+                if (a.direction == DIR_HORIZONTAL && P::HAS_SOURCE) lt += S[s];
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) {
+                    lt += MI * sD[n + NQ * i] * sF[(0 * NS + s) * Np + n + NQ * (j + NQ * k)];
+                    lt += MI * sD[n + NQ * j] * sF[(1 * NS + s) * Np + i + NQ * (n + NQ * k)];
+                }
+                T = a.beta != 0 ? a.alpha * lt + a.beta * Told : a.alpha * lt;
+            }
+            if (vt) {  // ::VerticalDirection kernel (:312-548); beta = true after the
+                       // horizontal call in EveryDirection (SpaceDiscretization.jl:1192)
+                double lt = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < NQ; ++kk) {
+                    lt += MI * sD[kk + NQ * k] * sF[(2 * NS + s) * Np + i + NQ * (j + NQ * kk)];
+                    if (kk == k && P::HAS_SOURCE) lt += S[s];
+                }
+                if (hz)
+                    T = a.alpha * lt + T;
+                else
+                    T = a.beta != 0 ? a.alpha * lt + a.beta * Told : a.alpha * lt;
+            }
+            sT[s * Np + tid] = T;
+        }
+    }
+    __syncthreads();
+    // ---- faces: dgsem_interface_tendency! ------------------------------------------
+    Vec<NS> lift;
+    int vidM = 0, fpair = -1;
+    if (tid < KD::NFT) {
+        const int f = tid / Nfp, n = tid % Nfp;
+        const bool on = f < 4 ? hz : vt;
+        if (on) {
+            const int facedir = f < 4 ? DIR_HORIZONTAL : DIR_VERTICAL;
+            FacePt fp;
+            face_setup<NQ>(a.g, e, f, n, fp);
+            Vec<NS> QM, QPn, QPd, flux;
+            Vec<NAUX> auxM, auxPn, auxPd;
+            Vec<NGF> gfM, gfP;
+            Vec<NHYP> hypM, hypP;
+            load_state<NS, Np>(QM, a.Q, fp.vidM, e);
+            load_state<NAUX, Np>(auxM, a.aux, fp.vidM, e);
+            load_state<NGF, Np>(gfM, a.gf, fp.vidM, e);
+            load_state<NS, Np>(QPn, a.Q, fp.vidP, fp.eP);
+            load_state<NAUX, Np>(auxPn, a.aux, fp.vidP, fp.eP);
+            load_state<NGF, Np>(gfP, a.gf, fp.vidP, fp.eP);
+#pragma unroll
+            for (int s = 0; s < NHYP; ++s) {
+                hypM[s] = a.hypgrad[fp.vidM + (int64_t)Np * (s + (int64_t)NHG * e)];
+                hypP[s] = a.hypgrad[fp.vidP + (int64_t)Np * (s + (int64_t)NHG * fp.eP)];
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) QPd[s] = QPn[s];
+#pragma unroll
+            for (int s = 0; s < NAUX; ++s) auxPd[s] = auxPn[s];
+            flux.negzero();
+            if (fp.bctag == 0) {
+                nf_first_order<P>(a.prm, a.nf_first, flux, fp.n, QM, auxM, QPn, auxPn, a.t,
+                                  facedir);
+                // CentralNumericalFluxSecondOrder  NumericalFluxes.jl:670-715
+                Vec<3 * NS> FM, FP;
+                FM.negzero();
+                P::flux_second_order(a.prm, FM, QM, gfM, hypM, auxM, a.t);
+                FP.negzero();
+                P::flux_second_order(a.prm, FP, QPd, gfP, hypP, auxPd, a.t);
+                const double nh0 = fp.n[0] / 2, nh1 = fp.n[1] / 2, nh2 = fp.n[2] / 2;
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    flux[s] += (FM[3 * s] + FP[3 * s]) * nh0 +
+                               (FM[3 * s + 1] + FP[3 * s + 1]) * nh1 +
+                               (FM[3 * s + 2] + FP[3 * s + 2]) * nh2;
+            } else {
+                Vec<NS> Q1;
+                Vec<NAUX> aux1;
+                Vec<NGF> gf1;
+                for (int s = 0; s < NS; ++s) Q1[s] = 0;
+                for (int s = 0; s < NAUX; ++s) aux1[s] = 0;
+                for (int s = 0; s < NGF; ++s) gf1[s] = 0;
+                if (f == 4) {  // bottom face: first interior node (:786-816)
+                    load_state<NS, Np>(Q1, a.Q, n + NQ * NQ, e);
+                    load_state<NAUX, Np>(aux1, a.aux, n + NQ * NQ, e);
+                    load_state<NGF, Np>(gf1, a.gf, n + NQ * NQ, e);
+                }
+                // numerical_boundary_flux_first_order!  NumericalFluxes.jl:163-205
+                P::boundary_state(a.prm, BS_FIRST, fp.bctag, QPn, auxPn, fp.n, QM, auxM, a.t, Q1,
+                                  aux1);
+                nf_first_order<P>(a.prm, a.nf_first, flux, fp.n, QM, auxM, QPn, auxPn, a.t,
+                                  facedir);
+                // normal_boundary_flux_second_order!  NumericalFluxes.jl:872-918
+                Vec<3 * NS> FP;
+                FP.negzero();
+                P::boundary_flux_second_order(a.prm, fp.bctag, FP, QPd, gfP, hypP, auxPd, fp.n, QM,
+                                              gfM, hypM, auxM, a.t, Q1, gf1, aux1);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    flux[s] +=
+                        FP[3 * s] * fp.n[0] + FP[3 * s + 1] * fp.n[1] + FP[3 * s + 2] * fp.n[2];
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) lift[s] = a.alpha * fp.vMI * fp.sM * flux[s];
+            vidM = fp.vidM;
+            fpair = f / 2;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {  // opposite faces touch disjoint nodes (:898-899)
+        if (fpair == p) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sT[s * Np + vidM] -= lift[s];
+        }
+        __syncthreads();
+    }
+    if (tid < Np) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t o = tid + (int64_t)Np * (s + (int64_t)NS * e);
+            const double T = sT[s * Np + tid];
+            if constexpr (LSRK) {  // update!: Q += rkb*dt*dQ; dQ *= rka
+                a.Qout[o] = a.Q[o] + a.rkb_dt * T;
+                a.tendency[o] = T * a.rka_next;
+            } else {
+                a.tendency[o] = T;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Gradient pass: volume_gradients! (:934-1328) + dgsem_interface_gradients! (:1365-1651)
+template <class P, int NQ>
+__global__ void __launch_bounds__(KDims<NQ>::NT) k_gradients(const PassArgs<P> a)
+{
+    using KD = KDims<NQ>;
+    constexpr int Np = KD::Np, Nfp = KD::Nfp, NS = P::NS, NAUX = P::NAUX, NGRAD = P::NGRAD,
+                  NGF = P::NGF, NGL = P::NGL, NHG = 3 * NGL, NACC = NGF + NHG;
+    __shared__ double sD[NQ * NQ];
+    __shared__ double sG[(NGRAD > 0 ? NGRAD : 1) * Np];
+    __shared__ double sA[(NACC > 0 ? NACC : 1) * Np];  // [gf..., hypgrad...][ijk]
+    const int tid = threadIdx.x;
+    const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
+    if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
+    const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
+    Vec<NS> lQ;
+    Vec<NAUX> laux;
+    if (tid < Np) {
+        load_state<NS, Np>(lQ, a.Q, tid, e);
+        load_state<NAUX, Np>(laux, a.aux, tid, e);
+        Vec<NGRAD> G;
+        G.negzero();
+        P::gradient_argument(a.prm, G, lQ, laux, a.t);
+#pragma unroll
+        for (int s = 0; s < NGRAD; ++s) sG[s * Np + tid] = G[s];
+    }
+    __syncthreads();
+    if (tid < Np) {
+        const int i = tid % NQ, j = (tid / NQ) % NQ, k = tid / (NQ * NQ);
+        const double *vg = a.g.vgeo + (int64_t)Np * a.g.nvgeo * e + tid;
+        Vec<3 * NGRAD> gh, gv;
+        gh.negzero();
+        gv.negzero();
+        if (hz) {
+            const double x11 = vg[XI1X1 * Np], x12 = vg[XI1X2 * Np], x13 = vg[XI1X3 * Np];
+            const double x21 = vg[XI2X1 * Np], x22 = vg[XI2X2 * Np], x23 = vg[XI2X3 * Np];
+#pragma unroll
+            for (int s = 0; s < NGRAD; ++s) {
+                double G1 = 0.0, G2 = 0.0;
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) {
+                    G1 += sD[i + NQ * n] * sG[s * Np + n + NQ * (j + NQ * k)];
+                    G2 += sD[j + NQ * n] * sG[s * Np + i + NQ * (n + NQ * k)];
+                }
+                gh[3 * s + 0] += x11 * G1;
+                gh[3 * s + 1] += x12 * G1;
+                gh[3 * s + 2] += x13 * G1;
+                gh[3 * s + 0] += x21 * G2;
+                gh[3 * s + 1] += x22 * G2;
+                gh[3 * s + 2] += x23 * G2;
+            }
+        }
+        if (vt) {
+            const double x31 = vg[XI3X1 * Np], x32 = vg[XI3X2 * Np], x33 = vg[XI3X3 * Np];
+#pragma unroll
+            for (int s = 0; s < NGRAD; ++s) {
+                double G3 = -0.0;
+#pragma unroll
+                for (int n = 0; n < NQ; ++n)
+                    G3 += sD[k + NQ * n] * sG[s * Np + i + NQ * (j + NQ * n)];
+                gv[3 * s + 0] += x31 * G3;
+                gv[3 * s + 1] += x32 * G3;
+                gv[3 * s + 2] += x33 * G3;
+            }
+        }
+        // hyperdiffusion gradients: "=" by the first kernel, "+=" by the vertical one
+#pragma unroll
+        for (int s = 0; s < NGL; ++s)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int q = d + 3 * P::hv_indexmap(s);
+                sA[(NGF + 3 * s + d) * Np + tid] = hz ? (vt ? gh[q] + gv[q] : gh[q]) : gv[q];
+            }
+        if constexpr (NGF > 0) {
+            Vec<NGF> o1, o2;
+            o1.negzero();
+            o2.negzero();
+            if (hz) P::gradient_flux(a.prm, o1, gh, lQ, laux, a.t);
+            if (vt) P::gradient_flux(a.prm, o2, gv, lQ, laux, a.t);
+#pragma unroll
+            for (int s = 0; s < NGF; ++s)
+                sA[s * Np + tid] = hz ? (vt ? o1[s] + o2[s] : o1[s]) : o2[s];
+        }
+    }
+    __syncthreads();
+    Vec<NACC> corr;
+    int vidM = 0, fpair = -1;
+    if (tid < KD::NFT) {
+        const int f = tid / Nfp, n = tid % Nfp;
+        const bool on = f < 4 ? hz : vt;
+        if (on) {
+            FacePt fp;
+            face_setup<NQ>(a.g, e, f, n, fp);
+            Vec<NS> QM, QP;
+            Vec<NAUX> auxM, auxP;
+            Vec<NGRAD> GM, GP;
+            load_state<NS, Np>(QM, a.Q, fp.vidM, e);
+            load_state<NAUX, Np>(auxM, a.aux, fp.vidM, e);
+            GM.negzero();
+            P::gradient_argument(a.prm, GM, QM, auxM, a.t);
+            load_state<NS, Np>(QP, a.Q, fp.vidP, fp.eP);
+            load_state<NAUX, Np>(auxP, a.aux, fp.vidP, fp.eP);
+            GP.negzero();
+            P::gradient_argument(a.prm, GP, QP, auxP, a.t);
+            Vec<NGF> lgf;
+            lgf.negzero();
+            Vec<3 * NGRAD> tg, nGM;
+            if (fp.bctag == 0) {  // CentralNumericalFluxGradient  NumericalFluxes.jl:67-83
+#pragma unroll
+                for (int s = 0; s < NGRAD; ++s)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) tg[d + 3 * s] = fp.n[d] * (GP[s] + GM[s]) / 2;
+            } else {  // numerical_boundary_flux_gradient!  NumericalFluxes.jl:85-123
+                Vec<NS> Q1;
+                Vec<NAUX> aux1;
+                for (int s = 0; s < NS; ++s) Q1[s] = 0;
+                for (int s = 0; s < NAUX; ++s) aux1[s] = 0;
+                if (f == 4) {
+                    load_state<NS, Np>(Q1, a.Q, n + NQ * NQ, e);
+                    load_state<NAUX, Np>(aux1, a.aux, n + NQ * NQ, e);
+                }
+                P::boundary_state(a.prm, BS_GRADIENT, fp.bctag, QP, auxP, fp.n, QM, auxM, a.t, Q1,
+                                  aux1);
+                P::gradient_argument(a.prm, GP, QP, auxP, a.t);
+#pragma unroll
+                for (int s = 0; s < NGRAD; ++s)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) tg[d + 3 * s] = fp.n[d] * GP[s];
+            }
+            if constexpr (NGF > 0) P::gradient_flux(a.prm, lgf, tg, QM, auxM, a.t);
+#pragma unroll
+            for (int s = 0; s < NGRAD; ++s)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) nGM[d + 3 * s] = fp.n[d] * GM[s];
+#pragma unroll
+            for (int s = 0; s < NGL; ++s)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int q = d + 3 * P::hv_indexmap(s);
+                    corr[NGF + 3 * s + d] = fp.vMI * fp.sM * (tg[q] - nGM[q]);
+                }
+            if constexpr (NGF > 0) {
+                Vec<NGF> visc;
+                for (int s = 0; s < NGF; ++s) visc[s] = 0;
+                P::gradient_flux(a.prm, visc, nGM, QM, auxM, a.t);
+#pragma unroll
+                for (int s = 0; s < NGF; ++s) corr[s] = fp.vMI * fp.sM * (lgf[s] - visc[s]);
+            }
+            vidM = fp.vidM;
+            fpair = f / 2;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        if (fpair == p) {
+#pragma unroll
+            for (int s = 0; s < NACC; ++s) sA[s * Np + vidM] += corr[s];
+        }
+        __syncthreads();
+    }
+    if (tid < Np) {
+#pragma unroll
+        for (int s = 0; s < NGF; ++s)
+            a.gf[tid + (int64_t)Np * (s + (int64_t)NGF * e)] = sA[s * Np + tid];
+#pragma unroll
+        for (int s = 0; s < NHG; ++s)
+            a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)] = sA[(NGF + s) * Np + tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Laplacian pass: volume_divergence_of_gradients! (:2132-2329) +
+// interface_divergence_of_gradients! (:2360-2494)
+template <class P, int NQ>
+__global__ void __launch_bounds__(KDims<NQ>::NT) k_divgrad(const PassArgs<P> a)
+{
+    using KD = KDims<NQ>;
+    constexpr int Np = KD::Np, Nfp = KD::Nfp, NAUX = P::NAUX, NGL = P::NGL, NHG = 3 * NGL,
+                  NHYP = P::NHYP, NG = NGL > 0 ? NGL : 1;
+    __shared__ double sD[NQ * NQ];
+    __shared__ double sC[3 * NG * Np];  // M * (xi_d . grad) [d][s][ijk]
+    __shared__ double sA[NG * Np];
+    const int tid = threadIdx.x;
+    const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
+    if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
+    const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
+    double MI = 0;
+    if (tid < Np) {
+        const double *vg = a.g.vgeo + (int64_t)Np * a.g.nvgeo * e + tid;
+        const double M = vg[VM * Np];
+        MI = vg[VMI * Np];
+        const double x11 = vg[XI1X1 * Np], x12 = vg[XI1X2 * Np], x13 = vg[XI1X3 * Np];
+        const double x21 = vg[XI2X1 * Np], x22 = vg[XI2X2 * Np], x23 = vg[XI2X3 * Np];
+        const double x31 = vg[XI3X1 * Np], x32 = vg[XI3X2 * Np], x33 = vg[XI3X3 * Np];
+#pragma unroll
+        for (int s = 0; s < NGL; ++s) {
+            const double G1 = a.hypgrad[tid + (int64_t)Np * (3 * s + 0 + (int64_t)NHG * e)];
+            const double G2 = a.hypgrad[tid + (int64_t)Np * (3 * s + 1 + (int64_t)NHG * e)];
+            const double G3 = a.hypgrad[tid + (int64_t)Np * (3 * s + 2 + (int64_t)NHG * e)];
+            sC[(0 * NG + s) * Np + tid] = M * (x11 * G1 + x12 * G2 + x13 * G3);
+            sC[(1 * NG + s) * Np + tid] = M * (x21 * G1 + x22 * G2 + x23 * G3);
+            sC[(2 * NG + s) * Np + tid] = M * (x31 * G1 + x32 * G2 + x33 * G3);
+        }
+    }
+    __syncthreads();
+    if (tid < Np) {
+        const int i = tid % NQ, j = (tid / NQ) % NQ, k = tid / (NQ * NQ);
+#pragma unroll
+        for (int s = 0; s < NGL; ++s) {
+            double dh = 0.0, dv = 0.0;
+            if (hz) {
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) {
+                    dh -= MI * sD[n + NQ * i] * sC[(0 * NG + s) * Np + n + NQ * (j + NQ * k)];
+                    dh -= MI * sD[n + NQ * j] * sC[(1 * NG + s) * Np + i + NQ * (n + NQ * k)];
+                }
+            }
+            if (vt) {
+#pragma unroll
+                for (int kk = 0; kk < NQ; ++kk)
+                    dv -= MI * sD[kk + NQ * k] * sC[(2 * NG + s) * Np + i + NQ * (j + NQ * kk)];
+            }
+            sA[s * Np + tid] = hz ? (vt ? dh + dv : dh) : dv;
+        }
+    }
+    __syncthreads();
+    Vec<NGL> corr;
+    int vidM = 0, fpair = -1;
+    if (tid < KD::NFT) {
+        const int f = tid / Nfp, n = tid % Nfp;
+        const bool on = f < 4 ? hz : vt;
+        if (on) {
+            FacePt fp;
+            face_setup<NQ>(a.g, e, f, n, fp);
+            Vec<NHG> gM, gP;
+#pragma unroll
+            for (int q = 0; q < NHG; ++q) {
+                gM[q] = a.hypgrad[fp.vidM + (int64_t)Np * (q + (int64_t)NHG * e)];
+                gP[q] = a.hypgrad[fp.vidP + (int64_t)Np * (q + (int64_t)NHG * fp.eP)];
+            }
+            if (fp.bctag != 0) {  // numerical_boundary_flux_divergence!  :732-763
+                Vec<NAUX> auxM, auxP;
+                load_state<NAUX, Np>(auxM, a.aux, fp.vidM, e);
+                load_state<NAUX, Np>(auxP, a.aux, fp.vidP, fp.eP);
+                P::boundary_state_divergence(a.prm, fp.bctag, gP, auxP, fp.n, gM, auxM, a.t);
+            }
+            // CentralNumericalFluxDivergence  NumericalFluxes.jl:720-730
+            const double nh0 = fp.n[0] / 2, nh1 = fp.n[1] / 2, nh2 = fp.n[2] / 2;
+#pragma unroll
+            for (int s = 0; s < NGL; ++s) {
+                const double ldiv = (gP[3 * s] + gM[3 * s]) * nh0 +
+                                    (gP[3 * s + 1] + gM[3 * s + 1]) * nh1 +
+                                    (gP[3 * s + 2] + gM[3 * s + 2]) * nh2;
+                corr[s] = fp.vMI * fp.sM * ldiv;
+            }
+            vidM = fp.vidM;
+            fpair = f / 2;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        if (fpair == p) {
+#pragma unroll
+            for (int s = 0; s < NGL; ++s) sA[s * Np + vidM] += corr[s];
+        }
+        __syncthreads();
+    }
+    if (tid < Np) {
+#pragma unroll
+        for (int s = 0; s < NGL; ++s)
+            a.hypdiv[tid + (int64_t)Np * (s + (int64_t)NHYP * e)] = sA[s * Np + tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Gradient-of-Laplacian pass: volume_gradients_of_laplacians! (:2525-2824) +
+// interface_gradients_of_laplacians! (:2859-3026)
+template <class P, int NQ>
+__global__ void __launch_bounds__(KDims<NQ>::NT) k_gradlap(const PassArgs<P> a)
+{
+    using KD = KDims<NQ>;
+    constexpr int Np = KD::Np, Nfp = KD::Nfp, NS = P::NS, NAUX = P::NAUX, NGL = P::NGL,
+                  NHG = 3 * NGL, NHYP = P::NHYP, NG = NGL > 0 ? NGL : 1,
+                  NH = NHYP > 0 ? NHYP : 1;
+    __shared__ double sD[NQ * NQ];
+    __shared__ double sL[NG * Np];
+    __shared__ double sA[NH * Np];
+    const int tid = threadIdx.x;
+    const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
+    if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
+    const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
+    if (tid < Np) {
+#pragma unroll
+        for (int s = 0; s < NGL; ++s)
+            sL[s * Np + tid] = a.hypdiv[tid + (int64_t)Np * (s + (int64_t)NHYP * e)];
+    }
+    __syncthreads();
+    if (tid < Np) {
+        const int i = tid % NQ, j = (tid / NQ) % NQ, k = tid / (NQ * NQ);
+        const double *vg = a.g.vgeo + (int64_t)Np * a.g.nvgeo * e + tid;
+        Vec<NS> lQ;
+        Vec<NAUX> laux;
+        load_state<NS, Np>(lQ, a.Q, tid, e);
+        load_state<NAUX, Np>(laux, a.aux, tid, e);
+        Vec<NHG> lh, lv;
+        lh.negzero();
+        lv.negzero();
+        if (hz) {
+            const double x11 = vg[XI1X1 * Np], x12 = vg[XI1X2 * Np], x13 = vg[XI1X3 * Np];
+            const double x21 = vg[XI2X1 * Np], x22 = vg[XI2X2 * Np], x23 = vg[XI2X3 * Np];
+#pragma unroll
+            for (int s = 0; s < NGL; ++s) {
+                double l1 = 0.0, l2 = 0.0;
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) {
+                    l1 += sD[i + NQ * n] * sL[s * Np + n + NQ * (j + NQ * k)];
+                    l2 += sD[j + NQ * n] * sL[s * Np + i + NQ * (n + NQ * k)];
+                }
+                lh[3 * s + 0] = x11 * l1;
+                lh[3 * s + 1] = x12 * l1;
+                lh[3 * s + 2] = x13 * l1;
+                lh[3 * s + 0] += x21 * l2;
+                lh[3 * s + 1] += x22 * l2;
+                lh[3 * s + 2] += x23 * l2;
+            }
+        }
+        if (vt) {
+            const double x31 = vg[XI3X1 * Np], x32 = vg[XI3X2 * Np], x33 = vg[XI3X3 * Np];
+#pragma unroll
+            for (int s = 0; s < NGL; ++s) {
+                double l3 = -0.0;
+#pragma unroll
+                for (int n = 0; n < NQ; ++n)
+                    l3 += sD[k + NQ * n] * sL[s * Np + i + NQ * (j + NQ * n)];
+                lv[3 * s + 0] += x31 * l3;
+                lv[3 * s + 1] += x32 * l3;
+                lv[3 * s + 2] += x33 * l3;
+            }
+        }
+        Vec<NHYP> h1, h2;
+        h1.negzero();
+        h2.negzero();
+        if (hz) P::post_gradient_laplacian(a.prm, h1, lh, lQ, laux, a.t);
+        if (vt) P::post_gradient_laplacian(a.prm, h2, lv, lQ, laux, a.t);
+#pragma unroll
+        for (int s = 0; s < NHYP; ++s) sA[s * Np + tid] = hz ? (vt ? h1[s] + h2[s] : h1[s]) : h2[s];
+    }
+    __syncthreads();
+    Vec<NHYP> corr;
+    int vidM = 0, fpair = -1;
+    if (tid < KD::NFT) {
+        const int f = tid / Nfp, n = tid % Nfp;
+        const bool on = f < 4 ? hz : vt;
+        if (on) {
+            FacePt fp;
+            face_setup<NQ>(a.g, e, f, n, fp);
+            Vec<NS> QM, QP;
+            Vec<NAUX> auxM, auxP;
+            Vec<NGL> lapM, lapP;
+            load_state<NS, Np>(QM, a.Q, fp.vidM, e);
+            load_state<NAUX, Np>(auxM, a.aux, fp.vidM, e);
+            load_state<NS, Np>(QP, a.Q, fp.vidP, fp.eP);
+            load_state<NAUX, Np>(auxP, a.aux, fp.vidP, fp.eP);
+#pragma unroll
+            for (int s = 0; s < NGL; ++s) {
+                lapM[s] = a.hypdiv[fp.vidM + (int64_t)Np * (s + (int64_t)NHYP * e)];
+                lapP[s] = a.hypdiv[fp.vidP + (int64_t)Np * (s + (int64_t)NHYP * fp.eP)];
+            }
+            if (fp.bctag != 0)  // numerical_boundary_flux_higher_order!  :792-832
+                P::boundary_state_higher_order(a.prm, fp.bctag, QP, auxP, lapP, fp.n, QM, auxM,
+                                               lapM, a.t);
+            // CentralNumericalFluxHigherOrder  NumericalFluxes.jl:768-790
+            Vec<NHG> G;
+#pragma unroll
+            for (int s = 0; s < NGL; ++s)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) G[d + 3 * s] = fp.n[d] * (lapP[s] - lapM[s]) / 2;
+            Vec<NHYP> lh;
+            for (int s = 0; s < NHYP; ++s) lh[s] = 0;
+            P::post_gradient_laplacian(a.prm, lh, G, QM, auxM, a.t);
+#pragma unroll
+            for (int s = 0; s < NHYP; ++s) corr[s] = fp.vMI * fp.sM * lh[s];
+            vidM = fp.vidM;
+            fpair = f / 2;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        if (fpair == p) {
+#pragma unroll
+            for (int s = 0; s < NHYP; ++s) sA[s * Np + vidM] += corr[s];
+        }
+        __syncthreads();
+    }
+    if (tid < Np) {
+#pragma unroll
+        for (int s = 0; s < NHYP; ++s)
+            a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)] = sA[s * Np + tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// kernel_nodal_update_auxiliary_state!  (:1769-1825); elements [e0, e1)
+template <class P, int NQ>
+__global__ void k_update_aux(typename P::Params prm, const double *Q, double *aux,
+                             const uint8_t *activedofs, double t, int64_t e0, int64_t e1)
+{
+    constexpr int Np = KDims<NQ>::Np, NS = P::NS, NAUX = P::NAUX;
+    const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e = e0 + I / Np;
+    const int n = (int)(I % Np);
+    if (e >= e1) return;
+    if (activedofs && !activedofs[n + e * Np]) return;
+    Vec<NS> lQ;
+    Vec<NAUX> laux;
+    load_state<NS, Np>(lQ, Q, n, e);
+    load_state<NAUX, Np>(laux, aux, n, e);
+    P::update_aux(prm, lQ, laux, t);
+#pragma unroll
+    for (int s = 0; s < NAUX; ++s) aux[n + (int64_t)Np * (s + (int64_t)NAUX * e)] = laux[s];
+}
+
+// ---------------------------------------------------------------------------------
+// kernel_fillsendbuf! / kernel_transferrecvbuf!  MPIStateArrays.jl:837-871
+static __global__ void k_fillsendbuf(double *__restrict__ sendbuf, const double *__restrict__ buf,
+                              const int64_t *__restrict__ vmapsend, int64_t nvmap, int Np,
+                              int nvar)
+{
+    const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= nvmap * nvar) return;
+    const int64_t i = I / nvar;
+    const int s = (int)(I % nvar);
+    const int64_t id = vmapsend[i] - 1;
+    const int64_t e = id / Np, n = id % Np;
+    sendbuf[s + (int64_t)nvar * i] = buf[n + (int64_t)Np * (s + (int64_t)nvar * e)];
+}
+static __global__ void k_transferrecvbuf(double *__restrict__ buf, const double *__restrict__ recvbuf,
+                                  const int64_t *__restrict__ vmaprecv, int64_t nvmap, int Np,
+                                  int nvar)
+{
+    const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= nvmap * nvar) return;
+    const int64_t i = I / nvar;
+    const int s = (int)(I % nvar);
+    const int64_t id = vmaprecv[i] - 1;
+    const int64_t e = id / Np, n = id % Np;
+    buf[n + (int64_t)Np * (s + (int64_t)nvar * e)] = recvbuf[s + (int64_t)nvar * i];
+}
+
+// ---------------------------------------------------------------------------------
+// local part of norm / euclidean_distance (MPIStateArrays.jl:583-644): per-block
+// partial sums in a fixed order (deterministic), finished on the host.
+static __global__ void k_wsum2(const double *__restrict__ A, const double *__restrict__ B,
+                        const double *__restrict__ vgeo, int nvgeo, int Np, int nvar,
+                        int64_t nreal, int weighted, double *__restrict__ partial)
+{
+    __shared__ double sh[256];
+    const int64_t total = (int64_t)Np * nvar * nreal;
+    double acc = 0.0;
+    for (int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; I < total;
+         I += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = I / ((int64_t)Np * nvar);
+        const int n = (int)(I % Np);
+        double d = A[I];
+        if (B) d -= B[I];
+        const double w = weighted ? vgeo[n + (int64_t)Np * (VM + (int64_t)nvgeo * e)] : 1.0;
+        acc += w * d * d;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+}  // namespace cmdg

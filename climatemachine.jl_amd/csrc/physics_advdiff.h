@@ -1,0 +1,232 @@
+// Device functor for the reference's test balance law AdvectionDiffusion{1}
+// (test/Numerics/DGMethods/advection_diffusion/advection_diffusion_model.jl:92-617)
+// and the problems that supply its coefficients and boundary data:
+//   problem 0  Pseudo1D                 pseudo1D_advection_diffusion.jl:28-68
+//   problem 1  ConstantHyperDiffusion   periodic_3D_hyperdiffusion.jl:29-63
+//
+// Parameter block (cmdg_desc.iparam / dparam):
+//   iparam[0]=num_equations (1)  [1]=advection [2]=diffusion [3]=hyperdiffusion
+//   iparam[4]=flux_bc [5]=problem [6]=nbc [7..13]=bc bitmask of boundary tag 1..7
+//   bc bit b: InhomogeneousBC{b} for b=0..3, HomogeneousBC{b-4} for b=4..7
+//   dparam: Pseudo1D n[3], alpha, beta, mu, delta | ConstantHyperDiffusion D[9], dim, dir
+//
+// Grad-type locals are 3 x nvar column-major: g[d + 3*s] (vars_wrappers.jl:52).
+#pragma once
+#include "cmdg_common.h"
+
+namespace cmdg {
+
+struct AdvDiffParams {
+    int flux_bc, problem, nbc;
+    int bc[8];
+    double d[16];
+};
+
+template <bool ADV, bool DIFF, bool HYPER>
+struct AdvDiff {
+    using Params = AdvDiffParams;
+    static constexpr int NS = 1;
+    static constexpr int NAUX = 3 + (ADV ? 3 : 0) + (DIFF ? 9 : 0) + (HYPER ? 9 : 0);
+    static constexpr int NGRAD = (DIFF || HYPER) ? 1 : 0;
+    static constexpr int NGF = DIFF ? 3 : 0;
+    static constexpr int NGL = HYPER ? 1 : 0;
+    static constexpr int NHYP = HYPER ? 3 : 0;
+    static constexpr int OU = 3, OD = 3 + (ADV ? 3 : 0), OH = OD + (DIFF ? 9 : 0);
+    static constexpr bool HAS_UPDATE_AUX = false;
+    static constexpr bool HAS_SOURCE = false;
+    __host__ __device__ static constexpr int hv_indexmap(int) { return 0; }
+
+    static constexpr int BC_INHOM(int o) { return 1 << o; }
+    static constexpr int BC_HOM(int o) { return 1 << (o + 4); }
+    static constexpr int BC_ANY(int o) { return BC_INHOM(o) | BC_HOM(o); }
+
+    static void make_params(Params &p, const int32_t *ip, const double *dp)
+    {
+        p.flux_bc = ip[4];
+        p.problem = ip[5];
+        p.nbc = ip[6];
+        for (int i = 0; i < 7; ++i) p.bc[i] = ip[7 + i];
+        p.bc[7] = 0;
+        for (int i = 0; i < 16; ++i) p.d[i] = dp[i];
+    }
+
+    // ---- problems ----------------------------------------------------------------
+    __device__ static double problem_rho(const Params &m, const double *x, double t)
+    {
+        if (m.problem == 0) {  // Pseudo1D initial_condition! (:42-52)
+            const double *n = m.d;
+            const double al = m.d[3], be = m.d[4], mu = m.d[5], de = m.d[6];
+            const double xn = n[0] * x[0] + n[1] * x[1] + n[2] * x[2];
+            const double a = xn - mu - al * t;
+            return exp(-(a * a) / (4 * be * (de + t))) / sqrt(1 + t / de);
+        } else if (m.problem == 1) {  // ConstantHyperDiffusion (:44-63)
+            const int dim = (int)m.d[9], dir = (int)m.d[10];
+            const double k[3] = {1, 2, 3};
+            double c;
+            if (dir == 0 || dir == 1) {
+                const int dd = dir == 0 ? dim : dim - 1;
+                double s2 = 0, skd = 0;
+                for (int i = 0; i < dd; ++i) s2 += k[i] * k[i];
+                for (int j = 0; j < dd; ++j)
+                    for (int i = 0; i < dd; ++i) skd += k[i] * k[j] * m.d[i + 3 * j];
+                c = s2 * skd;
+            } else {
+                c = k[dim - 1] * k[dim - 1] *
+                    (k[dim - 1] * k[dim - 1] * m.d[(dim - 1) + 3 * (dim - 1)]);
+            }
+            double kx = 0;
+            for (int i = 0; i < dim; ++i) kx += k[i] * x[i];
+            return sin(kx) * exp(-c * t);
+        }
+        return 0.0;
+    }
+    __device__ static void problem_grad(const Params &m, double *g, const double *x, double t)
+    {
+        if (m.problem == 0) {  // inhomogeneous_data!(Val(1), ::Pseudo1D, ...) (:54-68)
+            const double *n = m.d;
+            const double al = m.d[3], be = m.d[4], mu = m.d[5], de = m.d[6];
+            const double xn = n[0] * x[0] + n[1] * x[1] + n[2] * x[2];
+            const double a = xn - mu - al * t;
+            for (int i = 0; i < 3; ++i)
+                g[i] = -(2 * n[i] * a / (4 * be * (de + t)) *
+                         exp(-(a * a) / (4 * be * (de + t))) / sqrt(1 + t / de));
+        } else {
+            g[0] = g[1] = g[2] = 0.0;
+        }
+    }
+
+    // ---- balance law -------------------------------------------------------------
+    __device__ static void flux_first_order(const Params &, double *F, const double *Q,
+                                            const double *aux, double, int)
+    {
+        if constexpr (ADV)
+            for (int d = 0; d < 3; ++d) F[d] += aux[OU + d] * Q[0];
+    }
+    __device__ static void flux_second_order(const Params &, double *F, const double *,
+                                             const double *gf, const double *hyp, const double *,
+                                             double)
+    {
+        if constexpr (DIFF)
+            for (int d = 0; d < 3; ++d) F[d] += -gf[d];
+        if constexpr (HYPER)
+            for (int d = 0; d < 3; ++d) F[d] += hyp[d];
+    }
+    __device__ static void source(const Params &, double *, const double *, const double *,
+                                  const double *, double, int)
+    {
+    }
+    __device__ static void gradient_argument(const Params &, double *G, const double *Q,
+                                             const double *, double)
+    {
+        if constexpr (NGRAD > 0) G[0] = Q[0];
+    }
+    __device__ static void matvec3(double *o, const double *A, const double *v)
+    {
+        for (int i = 0; i < 3; ++i) o[i] = A[i] * v[0] + A[i + 3] * v[1] + A[i + 6] * v[2];
+    }
+    __device__ static void gradient_flux(const Params &, double *gf, const double *gradG,
+                                         const double *, const double *aux, double)
+    {
+        if constexpr (DIFF) matvec3(gf, aux + OD, gradG);
+    }
+    __device__ static void post_gradient_laplacian(const Params &, double *hyp,
+                                                   const double *gradlap, const double *,
+                                                   const double *aux, double)
+    {
+        if constexpr (HYPER) matvec3(hyp, aux + OH, gradlap);
+    }
+    __device__ static void wavespeed(const Params &, double *ws, const double *n, const double *,
+                                     const double *aux, double, int)
+    {
+        if constexpr (ADV)
+            ws[0] = fabs(n[0] * aux[OU] + n[1] * aux[OU + 1] + n[2] * aux[OU + 2]);
+        else
+            ws[0] = 0.0;
+    }
+    // boundary_state!(nf, bcs, m, stateP, auxP, nM, stateM, auxM, t, _...)  (:402-428)
+    __device__ static void boundary_state(const Params &m, int, int bctag, double *QP,
+                                          double *auxP, const double *, const double *QM,
+                                          const double *, double t, const double *,
+                                          const double *)
+    {
+        const int bc = m.bc[bctag - 1];
+        if (bc & BC_INHOM(0))
+            QP[0] = problem_rho(m, auxP, t);
+        else if (bc & BC_ANY(1))
+            QP[0] = QM[0];
+        else if (bc & BC_HOM(0))
+            QP[0] = 0.0;
+    }
+    // boundary_state!(::CentralNumericalFluxSecondOrder, ...) (:430-517) followed by
+    // flux_second_order! (NumericalFluxes.jl:921-967), or the flux_bc method (:519-567)
+    __device__ static void boundary_flux_second_order(
+        const Params &m, int bctag, double *F, double *QP, double *gfP, double *hypP,
+        double *auxP, const double *, const double *QM, const double *gfM, const double *hypM,
+        const double *auxM, double t, const double *, const double *, const double *)
+    {
+        const int bc = m.bc[bctag - 1];
+        double g[3];
+        if constexpr (!DIFF && !HYPER) {
+            return;
+        } else {
+            if (m.flux_bc) {
+                if (bc & BC_ANY(0)) {
+                    flux_second_order(m, F, QM, gfM, hypM, auxM, t);
+                } else if (bc & BC_INHOM(1)) {
+                    problem_grad(m, g, auxM, t);
+                    const double *D = auxM + OD;
+                    for (int i = 0; i < 3; ++i)
+                        F[i] = -D[i] * g[0] + -D[i + 3] * g[1] + -D[i + 6] * g[2];
+                } else if (bc & BC_HOM(1)) {
+                    F[0] = F[1] = F[2] = 0.0;
+                }
+                return;
+            }
+            if constexpr (DIFF) {
+                if (bc & BC_ANY(0)) {
+                    for (int d = 0; d < 3; ++d) gfP[d] = gfM[d];
+                } else if (bc & BC_INHOM(1)) {
+                    problem_grad(m, g, auxM, t);
+                    matvec3(gfP, auxM + OD, g);
+                } else if (bc & BC_HOM(1)) {
+                    g[0] = g[1] = g[2] = 0.0;
+                    matvec3(gfP, auxM + OD, g);
+                }
+            }
+            if constexpr (HYPER) {
+                if (bc & BC_ANY(3)) {
+                    g[0] = g[1] = g[2] = 0.0;
+                    matvec3(hypP, auxM + OH, g);
+                }
+            }
+            flux_second_order(m, F, QP, gfP, hypP, auxP, t);
+        }
+    }
+    // boundary_state!(::CentralNumericalFluxDivergence, ...) (:569-591)
+    __device__ static void boundary_state_divergence(const Params &m, int bctag, double *gradP,
+                                                     double *, const double *, const double *,
+                                                     const double *auxM, double t)
+    {
+        if constexpr (HYPER) {
+            const int bc = m.bc[bctag - 1];
+            if (bc & BC_INHOM(1))
+                problem_grad(m, gradP, auxM, t);
+            else if (bc & BC_HOM(1))
+                gradP[0] = gradP[1] = gradP[2] = 0.0;
+        }
+    }
+    // boundary_state!(::CentralNumericalFluxHigherOrder, ...) (:593-617)
+    __device__ static void boundary_state_higher_order(const Params &m, int bctag, double *,
+                                                       double *, double *lapP, const double *,
+                                                       const double *, const double *,
+                                                       const double *, double)
+    {
+        if constexpr (HYPER) {
+            const int bc = m.bc[bctag - 1];
+            if (bc & BC_ANY(2)) lapP[0] = 0.0;
+        }
+    }
+    __device__ static void update_aux(const Params &, const double *, double *, double) {}
+};
+
+}  // namespace cmdg

@@ -1,0 +1,238 @@
+"""Host-side mirror of the reference's ``DGModel`` operator API, backed by libcmdg.
+
+Reference: ``DGModel(balance_law, grid, nf_first, nf_second, nf_gradient; direction,
+diffusion_direction, state_auxiliary, ...)`` ``src/Numerics/DGMethods/DGModel.jl:22-65``;
+the callable ``(dg)(tendency, Q, _, t, alpha, beta)`` ``:85-427``; ``init_ode_state``
+``SpaceDiscretization.jl:79-148``; ``norm`` / ``euclidean_distance``
+``src/Arrays/MPIStateArrays.jl:583-644``.
+
+State arrays are torch float64 CUDA(=HIP) tensors of numpy-style shape
+``(nelem, nstate, Np)`` -- the memory image of the reference's ``(Np, nstate, nelem)``.
+torch is used for device memory only; every kernel is in libcmdg.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .balancelaws import EveryDirection, RusanovNumericalFlux
+
+__all__ = ["DGModel", "connect_local", "group_rhs", "group_lsrk_run"]
+
+
+def _dev(a, device, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(device)
+
+
+class DGModel:
+    def __init__(self, balance_law, grid, numerical_flux_first_order=RusanovNumericalFlux,
+                 direction=EveryDirection, diffusion_direction=None, device="cuda:0",
+                 state_auxiliary=None):
+        if not torch.cuda.is_available():
+            raise _lib.CmdgError("DGModel needs a HIP device; there is no CPU fallback")
+        L = _lib.lib()
+        self.L = L
+        self.balance_law = balance_law
+        self.grid = grid
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.direction = direction
+        self.diffusion_direction = direction if diffusion_direction is None else diffusion_direction
+        law, g = balance_law, grid
+        if g.dim != 3 or len(set(g.N)) != 1:
+            raise _lib.CmdgError("libcmdg: 3-D grids with one polynomial order only")
+        ip, dp = law.descriptor()
+        counts = (C.c_int32 * 6)()
+        ipa = (C.c_int32 * 16)(*[int(v) for v in ip])
+        _lib.check(L.cmdg_physics_counts(law.physics_id, C.cast(ipa, C.c_void_p), C.cast(counts, C.c_void_p)))
+        want = (law.ns, law.naux, law.ngrad, law.ngradflux, law.ngradlap, law.nhyper)
+        if tuple(counts) != want:
+            raise _lib.CmdgError("state counts differ: host %s device functor %s" % (want, tuple(counts)))
+        dev = self.device
+        # grid tables (reference layouts)
+        self._vgeo = _dev(g.vgeo, dev)
+        self._sgeo = _dev(g.sgeo, dev)
+        self._vmapM = _dev(g.vmapM, dev)
+        self._vmapP = _dev(g.vmapP, dev)
+        self._elemtobndy = _dev(g.elemtobndy, dev)
+        self._interior = _dev(np.asarray(g.interiorelems, dtype=np.int64), dev)
+        self._exterior = _dev(np.asarray(g.exteriorelems, dtype=np.int64), dev)
+        self._active = _dev(g.activedofs.astype(np.uint8), dev)
+        self._D = np.ascontiguousarray(g.D[0].T, dtype=np.float64)   # column-major (Nq, Nq)
+        self._vmapsend = _dev(np.asarray(g.vmapsend, dtype=np.int64), dev)
+        self._vmaprecv = _dev(np.asarray(g.vmaprecv, dtype=np.int64), dev)
+        nn = len(g.nabrtorank)
+        self._nabr = np.asarray(g.nabrtorank, dtype=np.int32)
+        self._nsend = np.asarray(g.nabrtovmapsend, dtype=np.int64).reshape(-1)
+        self._nrecv = np.asarray(g.nabrtovmaprecv, dtype=np.int64).reshape(-1)
+        aux = law.init_state_auxiliary(g) if state_auxiliary is None else state_auxiliary
+        self.state_auxiliary = _dev(aux, dev) if isinstance(aux, np.ndarray) else aux
+        ne, Np = g.nelem, g.Np
+        self.state_gradient_flux = torch.zeros((ne, max(law.ngradflux, 1), Np), dtype=torch.float64, device=dev)
+        self.Qhypervisc_grad = torch.zeros((ne, max(3 * law.ngradlap, 1), Np), dtype=torch.float64, device=dev)
+        self.Qhypervisc_div = torch.zeros((ne, max(law.nhyper, 1), Np), dtype=torch.float64, device=dev)
+        d = _lib.CmdgDesc()
+        d.dim = 3
+        d.N[:] = list(g.N)
+        d.nreal, d.nghost = g.nreal, g.nelem - g.nreal
+        d.nvgeo = g.vgeo.shape[1]
+        d.physics_id = law.physics_id
+        d.iparam[:] = [int(v) for v in ip]
+        d.dparam[:] = [float(v) for v in dp]
+        d.nf_first = int(numerical_flux_first_order)
+        d.direction, d.diffusion_direction = int(self.direction), int(self.diffusion_direction)
+        d.stacked = int(bool(g.topology.isstacked))
+        d.vgeo, d.sgeo = self._vgeo.data_ptr(), self._sgeo.data_ptr()
+        d.vmapM, d.vmapP = self._vmapM.data_ptr(), self._vmapP.data_ptr()
+        d.elemtobndy = self._elemtobndy.data_ptr()
+        d.interiorelems, d.ninterior = self._interior.data_ptr(), self._interior.numel()
+        d.exteriorelems, d.nexterior = self._exterior.data_ptr(), self._exterior.numel()
+        d.activedofs = self._active.data_ptr()
+        d.D = self._D.ctypes.data
+        d.vmapsend, d.nvmapsend = self._vmapsend.data_ptr(), self._vmapsend.numel()
+        d.vmaprecv, d.nvmaprecv = self._vmaprecv.data_ptr(), self._vmaprecv.numel()
+        d.nnabr = nn
+        d.nabrtorank = self._nabr.ctypes.data
+        d.nabrtovmapsend = self._nsend.ctypes.data
+        d.nabrtovmaprecv = self._nrecv.ctypes.data
+        d.state_auxiliary = self.state_auxiliary.data_ptr()
+        d.state_gradient_flux = self.state_gradient_flux.data_ptr()
+        d.Qhypervisc_grad = self.Qhypervisc_grad.data_ptr()
+        d.Qhypervisc_div = self.Qhypervisc_div.data_ptr()
+        torch.cuda.synchronize(dev)          # tables uploaded on torch's stream
+        h = C.c_void_p()
+        _lib.check(L.cmdg_create(C.byref(d), C.byref(h)))
+        self.handle = h
+        self._desc = d
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.cmdg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state helpers --------------------------------------------------------------
+    def create_state(self, nstate=None):
+        ns = self.balance_law.ns if nstate is None else nstate
+        return torch.zeros((self.grid.nelem, ns, self.grid.Np), dtype=torch.float64,
+                           device=self.device)
+
+    def init_ode_state(self, t=0.0):
+        """``init_ode_state(dg, t)``: one-time, on the host."""
+        aux = self.state_auxiliary.cpu().numpy()
+        Q = self.balance_law.init_state_prognostic(self.grid, aux, t)
+        q = _dev(Q, self.device)
+        torch.cuda.synchronize(self.device)
+        return q
+
+    # -- the operator ---------------------------------------------------------------
+    def __call__(self, tendency, Q, t, alpha=1.0, beta=0.0, increment=None):
+        """``dg(tendency, Q, nothing, t, alpha, beta)``; the 4-argument form with
+        ``increment`` maps to ``(alpha, beta) = (1, increment)`` (SpaceDiscretization.jl:68-77)."""
+        if increment is not None:
+            alpha, beta = 1.0, float(bool(increment))
+        self._torch_ready()
+        _lib.check(self.L.cmdg_rhs(self.handle, tendency.data_ptr(), Q.data_ptr(), float(t),
+                                   float(alpha), float(beta)), self.handle)
+
+    def synchronize(self):
+        _lib.check(self.L.cmdg_synchronize(self.handle), self.handle)
+
+    def _torch_ready(self):
+        """libcmdg runs on its own HIP streams: anything torch enqueued on its current
+        stream (fills, copies of the arrays we are handed) must have finished first."""
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def lsrk_run(self, Q, dQ, t, dt, nsteps, rka, rkb, rkc):
+        a = (C.c_double * len(rka))(*rka)
+        b = (C.c_double * len(rkb))(*rkb)
+        c = (C.c_double * len(rkc))(*rkc)
+        self._torch_ready()
+        _lib.check(self.L.cmdg_lsrk_run(
+            self.handle, Q.data_ptr(), dQ.data_ptr(), float(t), float(dt), int(nsteps),
+            len(rka), C.cast(a, C.c_void_p), C.cast(b, C.c_void_p), C.cast(c, C.c_void_p)),
+            self.handle)
+
+    # -- reductions (local part) ------------------------------------------------------
+    def norm2_local(self, A, weighted=True):
+        out = C.c_double()
+        self._torch_ready()
+        _lib.check(self.L.cmdg_norm2_local(self.handle, A.data_ptr(), A.shape[1], int(weighted),
+                                           C.cast(C.byref(out), C.c_void_p)), self.handle)
+        return out.value
+
+    def distance2_local(self, A, B):
+        out = C.c_double()
+        self._torch_ready()
+        _lib.check(self.L.cmdg_distance2_local(self.handle, A.data_ptr(), B.data_ptr(),
+                                               A.shape[1], C.cast(C.byref(out), C.c_void_p)),
+                   self.handle)
+        return out.value
+
+    def norm(self, A, weighted=True):
+        return math.sqrt(self.norm2_local(A, weighted))
+
+    def euclidean_distance(self, A, B):
+        return math.sqrt(self.distance2_local(A, B))
+
+    # -- measurement ------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        _lib.check(self.L.cmdg_profile_enable(self.handle, int(on)), self.handle)
+
+    def profile_reset(self):
+        _lib.check(self.L.cmdg_profile_reset(self.handle), self.handle)
+
+    def profile_get(self, kernel):
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(self.L.cmdg_profile_get(self.handle, _lib.CMDG_K[kernel],
+                                           C.cast(C.byref(ms), C.c_void_p),
+                                           C.cast(C.byref(n), C.c_void_p)), self.handle)
+        return ms.value, n.value
+
+
+def _harr(dgs):
+    return (C.c_void_p * len(dgs))(*[d.handle for d in dgs])
+
+
+def _parr(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def connect_local(dgs):
+    """Connect the per-rank models of one process (rank r = dgs[r]) through device
+    copies: the single-GPU rehearsal of the multi-GPU halo path."""
+    L = _lib.lib()
+    _lib.check(L.cmdg_comm_connect_local(C.cast(_harr(dgs), C.c_void_p), len(dgs)), dgs[0].handle)
+
+
+def group_rhs(dgs, tendencies, Qs, t, alpha=1.0, beta=0.0):
+    L = _lib.lib()
+    dgs[0]._torch_ready()
+    _lib.check(L.cmdg_group_rhs(C.cast(_harr(dgs), C.c_void_p), len(dgs),
+                                C.cast(_parr(tendencies), C.c_void_p),
+                                C.cast(_parr(Qs), C.c_void_p), float(t), float(alpha),
+                                float(beta)), dgs[0].handle)
+    for d in dgs:
+        d.synchronize()
+
+
+def group_lsrk_run(dgs, Qs, dQs, t, dt, nsteps, rka, rkb, rkc):
+    L = _lib.lib()
+    a = (C.c_double * len(rka))(*rka)
+    b = (C.c_double * len(rkb))(*rkb)
+    c = (C.c_double * len(rkc))(*rkc)
+    dgs[0]._torch_ready()
+    _lib.check(L.cmdg_group_lsrk_run(
+        C.cast(_harr(dgs), C.c_void_p), len(dgs), C.cast(_parr(Qs), C.c_void_p),
+        C.cast(_parr(dQs), C.c_void_p), float(t), float(dt), int(nsteps), len(rka),
+        C.cast(a, C.c_void_p), C.cast(b, C.c_void_p), C.cast(c, C.c_void_p)), dgs[0].handle)

@@ -119,12 +119,15 @@ def _stack(base, stacksize, dim, elemtocoord, elemtoordr_map, vert_nbr, vert_bnd
     nabrtorecv = [(stacksize * (a - 1) + 1, stacksize * b) for a, b in base.nabrtorecv]
     nabrtosend = [(stacksize * (a - 1) + 1, stacksize * b) for a, b in base.nabrtosend]
     b2e, b2f = bm.enumerateboundaryfaces(elemtoelem, elemtobndy, periodicity, boundary)
+    gl = None
+    if base.globalelems is not None:      # global id of a stacked element (test bookkeeping)
+        gl = (stacksize * (np.asarray(base.globalelems)[:, None] - 1) + j[None, :]).reshape(-1)
     conn = dict(nelem=nelem, nreal=nreal, nghost=nghost, ghostfaces=ghostfaces,
                 sendelems=sendelems, sendfaces=sendfaces, elemtocoord=elemtocoord,
                 elemtoelem=elemtoelem, elemtoface=elemtoface, elemtoordr=elemtoordr,
                 elemtobndy=elemtobndy, nabrtorank=base.nabrtorank,
                 nabrtorecv=nabrtorecv, nabrtosend=nabrtosend,
-                globalelems=None)
+                globalelems=gl)
     return Topology(dim, conn, stacksize=stacksize, periodicstack=periodicstack,
                     bndytoelem=b2e, bndytoface=b2f, rank=rank, size=size)
 

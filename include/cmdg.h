@@ -1,0 +1,165 @@
+/* libcmdg -- MI355X-native DG right-hand side + low-storage Runge-Kutta stepping for
+ * ClimateMachine-style balance laws.  C ABI: plain pointers and sizes, no C++ or
+ * torch types.  One handle per (rank, GPU); a handle is driven by one host thread.
+ *
+ * The reference (ClimateMachine.jl, Julia) has no FFI seam on this path: the seam
+ * is the Julia callable `(dg::DGModel)(tendency, Q, _, t, alpha, beta)`.  Each
+ * entry point below names the reference interface it replaces (paths relative to
+ * the reference root).  INTEGRATION.md shows the Julia `ccall` stubs.
+ *
+ * All arrays use the reference's column-major layouts and 1-based integer tables:
+ *   state arrays (Np, nstate, nelem) Float64, nelem = nreal + nghost, real first
+ *   vgeo (Np, nvgeo, nelem)   sgeo (5, Nfp, nface, nelem)     [Grids.jl:76-146]
+ *   vmapM/vmapP (Nfp, nface, nelem) Int64                     [Grids.jl:559-637]
+ *   elemtobndy (nface, nelem) Int64                           [Topologies.jl]
+ * "device" pointers must stay valid from cmdg_create to cmdg_destroy.
+ * Every function returns 0 (CMDG_OK) or a negative cmdg_status; none throws.
+ */
+#ifndef CMDG_H
+#define CMDG_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cmdg_context *cmdg_handle;
+
+typedef enum cmdg_status {
+    CMDG_OK = 0,
+    CMDG_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
+    CMDG_ERR_HIP = -2,         /* a HIP runtime call failed */
+    CMDG_ERR_NO_DEVICE = -3,   /* no gfx950 device visible */
+    CMDG_ERR_COMM = -4,        /* RCCL / transport failure */
+    CMDG_ERR_UNSUPPORTED = -5  /* physics / polynomial order not compiled in */
+} cmdg_status;
+
+/* directions (src/Numerics/Mesh/Grids.jl Direction types) */
+enum { CMDG_EVERY_DIRECTION = 0, CMDG_HORIZONTAL_DIRECTION = 1, CMDG_VERTICAL_DIRECTION = 2 };
+/* first-order numerical flux (NumericalFluxes.jl:219,298); second order and gradient
+ * fluxes are the central ones (:668, :65), as in every configuration in scope */
+enum { CMDG_RUSANOV = 0, CMDG_CENTRAL_FIRST_ORDER = 1 };
+/* balance laws carried as device functors (pointwise Julia physics cannot cross a C ABI) */
+enum { CMDG_PHYSICS_ADVECTION_DIFFUSION = 1, CMDG_PHYSICS_DRY_ATMOS = 2 };
+
+/* Construction record: the fields of `DGModel(balance_law, grid, nf1, nf2, nfgrad;
+ * state_auxiliary, state_gradient_flux, states_higher_order, direction,
+ * diffusion_direction)` (src/Numerics/DGMethods/DGModel.jl:22-65) and of the
+ * `DiscontinuousSpectralElementGrid` it reads (src/Numerics/Mesh/Grids.jl:187-264). */
+typedef struct cmdg_desc {
+    int32_t dim;                 /* 3 */
+    int32_t N[3];                /* polynomial orders; N[0] == N[1] == N[2] */
+    int64_t nreal, nghost;       /* topology.realelems / ghostelems counts */
+    int32_t nvgeo;               /* columns of vgeo (25: GeometricFactors.jl:60-67) */
+    int32_t physics_id;          /* CMDG_PHYSICS_* */
+    int32_t iparam[16];          /* law parameters, see csrc/physics_*.h */
+    double dparam[32];
+    int32_t nf_first;            /* CMDG_RUSANOV | CMDG_CENTRAL_FIRST_ORDER */
+    int32_t direction;           /* dg.direction */
+    int32_t diffusion_direction; /* dg.diffusion_direction */
+    int32_t stacked;             /* isstacked(grid.topology): with a vertical-only
+                                    direction no halo is exchanged (DGModel.jl:104-108) */
+    /* grid tables, device pointers */
+    const double *vgeo, *sgeo;
+    const int64_t *vmapM, *vmapP, *elemtobndy;
+    const int64_t *interiorelems;
+    int64_t ninterior;           /* grid.interiorelems (1-based) */
+    const int64_t *exteriorelems;
+    int64_t nexterior;           /* grid.exteriorelems (1-based) */
+    const uint8_t *activedofs;   /* (Np*nelem) grid.activedofs, may be NULL if unused */
+    const double *D;             /* HOST pointer, (Nq, Nq) column-major, grid.D[1] */
+    /* halo tables: grid.vmapsend / vmaprecv (device) and per-neighbour ranges (host) */
+    const int64_t *vmapsend;
+    int64_t nvmapsend;
+    const int64_t *vmaprecv;
+    int64_t nvmaprecv;
+    int32_t nnabr;
+    const int32_t *nabrtorank;       /* HOST, nnabr */
+    const int64_t *nabrtovmapsend;   /* HOST, 2*nnabr: first,last (1-based inclusive) */
+    const int64_t *nabrtovmaprecv;   /* HOST, 2*nnabr */
+    /* arrays owned by the `dg` in the reference; device pointers, caller-owned.
+     * state_auxiliary is required; the other three may be NULL (library allocates). */
+    double *state_auxiliary;       /* (Np, naux, nelem) */
+    double *state_gradient_flux;   /* (Np, ngradflux, nelem) */
+    double *Qhypervisc_grad;       /* (Np, 3*ngradlap, nelem)  create_states.jl:22-26 */
+    double *Qhypervisc_div;        /* (Np, nhyper, nelem) */
+} cmdg_desc;
+
+/* ---- queries ------------------------------------------------------------------ */
+const char *cmdg_version(void);
+const char *cmdg_status_string(int status);
+/* number_states(balance_law, st) for st = Prognostic, Auxiliary, Gradient, GradientFlux,
+ * GradientLaplacian, Hyperdiffusive (src/BalanceLaws/state_types.jl:40-108) -> out[6] */
+int cmdg_physics_counts(int32_t physics_id, const int32_t *iparam, int32_t out[6]);
+
+/* ---- lifetime ----------------------------------------------------------------- */
+/* replaces DGModel(...) construction, DGModel.jl:22-65 */
+int cmdg_create(const cmdg_desc *desc, cmdg_handle *out);
+int cmdg_destroy(cmdg_handle h);
+/* message of the last failure on this handle (never NULL) */
+const char *cmdg_last_error(cmdg_handle h);
+
+/* ---- the hot path ------------------------------------------------------------- */
+/* replaces (dg::DGModel)(tendency, Q, _, t, alpha, beta), DGModel.jl:85-427:
+ *   tendency .= alpha * dQdt(Q, t) + beta * tendency   on real elements;
+ * ghost face nodes of Q are refreshed as a side effect; returns when all device work is
+ * complete (DGModel.jl:426). */
+int cmdg_rhs(cmdg_handle h, double *tendency, double *Q, double t, double alpha, double beta);
+/* same, enqueued on the handle's stream without the final wait */
+int cmdg_rhs_async(cmdg_handle h, double *tendency, double *Q, double t, double alpha,
+                   double beta);
+/* replaces dostep!(Q, lsrk::LowStorageRungeKutta2N, p, time) with its update! kernel,
+ * LowStorageRungeKuttaMethod.jl:102-158: for s in 1:nstages
+ *   dQ = rhs(Q, t + rkc[s] dt) + dQ;  Q += rkb[s] dt dQ;  dQ *= rka[s % nstages + 1]
+ * (the update is fused into the last kernel of each stage).  Asynchronous: call
+ * cmdg_synchronize before reading Q on another stream or on the host. */
+int cmdg_lsrk_step(cmdg_handle h, double *Q, double *dQ, double t, double dt, int32_t nstages,
+                   const double *rka, const double *rkb, const double *rkc);
+/* nsteps back-to-back steps of size dt starting at t (solve! loop body,
+ * ODESolvers.jl:110-158 without callbacks) */
+int cmdg_lsrk_run(cmdg_handle h, double *Q, double *dQ, double t, double dt, int64_t nsteps,
+                  int32_t nstages, const double *rka, const double *rkb, const double *rkc);
+int cmdg_synchronize(cmdg_handle h);
+
+/* ---- halo (MPIStateArrays.jl:411-514, 837-871) -------------------------------- */
+/* begin_ghost_exchange!: pack face nodes of `array` (Np, nstate, nelem) and post the
+ * sends/receives; end_ghost_exchange!: wait and unpack into the ghost elements. */
+int cmdg_halo_begin(cmdg_handle h, double *array, int32_t nstate);
+int cmdg_halo_end(cmdg_handle h, double *array, int32_t nstate);
+/* Transport set-up.  Multi-process: RCCL point-to-point; `unique_id` is the 128-byte
+ * ncclUniqueId made by cmdg_comm_unique_id on rank 0 and broadcast by the caller. */
+int cmdg_comm_unique_id(void *out128);
+int cmdg_comm_init_rccl(cmdg_handle h, const void *unique_id128, int32_t rank, int32_t nranks);
+/* Single-process: connect n handles (handle r plays rank r) through device copies. */
+int cmdg_comm_connect_local(cmdg_handle *handles, int32_t n);
+
+/* Lock-step drivers for handles connected with cmdg_comm_connect_local (one host thread
+ * plays every rank): arrays of n per-rank pointers. */
+int cmdg_group_rhs(cmdg_handle *handles, int32_t n, double **tendency, double **Q, double t,
+                   double alpha, double beta);
+int cmdg_group_lsrk_run(cmdg_handle *handles, int32_t n, double **Q, double **dQ, double t,
+                        double dt, int64_t nsteps, int32_t nstages, const double *rka,
+                        const double *rkb, const double *rkc);
+
+/* ---- reductions (MPIStateArrays.jl:583-644), local part; caller all-reduces ---- */
+/* out = sum over real elements of M .* A.^2  (weighted) or A.^2 */
+int cmdg_norm2_local(cmdg_handle h, const double *A, int32_t nstate, int32_t weighted,
+                     double *out_host);
+/* out = sum over real elements of M .* (A - B).^2 */
+int cmdg_distance2_local(cmdg_handle h, const double *A, const double *B, int32_t nstate,
+                         double *out_host);
+
+/* ---- measurement --------------------------------------------------------------- */
+enum {
+    CMDG_K_GRADIENTS = 0, CMDG_K_DIVGRAD = 1, CMDG_K_GRADLAP = 2, CMDG_K_TENDENCY = 3,
+    CMDG_K_PACK = 4, CMDG_K_UNPACK = 5, CMDG_K_UPDATE_AUX = 6, CMDG_K_COUNT = 7
+};
+/* bracket every launch with HIP events on the launch stream (off by default) */
+int cmdg_profile_enable(cmdg_handle h, int32_t on);
+int cmdg_profile_get(cmdg_handle h, int32_t kernel, double *total_ms, int64_t *launches);
+int cmdg_profile_reset(cmdg_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMDG_H */

@@ -1,0 +1,57 @@
+"""libcmdg.so loads on a machine without a GPU and exports every symbol include/cmdg.h
+declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+from cmdg_loader import cm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "cmdg.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cmdg_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = declared_symbols()
+    assert len(names) >= 20
+    L = ctypes.CDLL(cm._lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), "libcmdg.so lacks %s" % n
+    bound = {s[0] for s in cm._lib.SYMBOLS}
+    assert set(names) == bound, set(names) ^ bound
+
+
+def test_queries_work_without_a_gpu():
+    L = cm._lib.lib()
+    assert b"gfx950" in L.cmdg_version()
+    ip = (ctypes.c_int32 * 16)(1, 1, 1, 0)
+    out = (ctypes.c_int32 * 6)()
+    assert L.cmdg_physics_counts(1, ctypes.cast(ip, ctypes.c_void_p),
+                                 ctypes.cast(out, ctypes.c_void_p)) == 0
+    assert list(out) == [1, 15, 1, 3, 0, 0]
+    assert L.cmdg_physics_counts(99, ctypes.cast(ip, ctypes.c_void_p),
+                                 ctypes.cast(out, ctypes.c_void_p)) == -5
+    assert L.cmdg_status_string(-5) == b"unsupported physics / polynomial order"
+
+
+def test_desc_struct_matches_header_field_order():
+    txt = open(os.path.join(ROOT, "include", "cmdg.h")).read()
+    body = txt[txt.index("typedef struct cmdg_desc {"):txt.index("} cmdg_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for stmt in body.split(";"):
+        stmt = stmt.strip()
+        if not stmt or stmt.startswith("typedef"):
+            continue
+        decl = stmt.split("\n")[-1] if "{" in stmt else stmt
+        decl = decl.replace("{", "")
+        names = re.sub(r"^(const\s+)?\w+\s+", "", decl.strip())
+        for nm in names.split(","):
+            nm = re.sub(r"\[.*\]", "", nm).replace("*", "").strip()
+            if nm:
+                fields.append(nm)
+    assert fields == [f[0] for f in cm._lib.CmdgDesc._fields_], fields

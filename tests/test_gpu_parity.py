@@ -1,0 +1,136 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and with the reference's
+golden values.  Needs a real MI355X: run with ``-m gpu``.
+
+Tolerance: north star asks tendency L-inf relative error < 1e-12 in fp64; the kernels keep
+the reference's summation order, so the observed differences are ~1e-16 (only libm's
+exp/sin differ)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import pseudo1d_setup, rel_linf
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_values.json")))
+DIRS = {0: "EveryDirection", 1: "HorizontalDirection", 2: "VerticalDirection"}
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "no HIP device: the product path has no CPU fallback"
+    return t
+
+
+def _gpu(torch, a):
+    x = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    torch.cuda.synchronize()
+    return x
+
+
+@pytest.mark.parametrize("flux_bc", [False, True])
+@pytest.mark.parametrize("direction", [0, 1, 2])
+def test_tendency_matches_oracle(cm, oracle, torch, direction, flux_bc):
+    law, grid, _ = pseudo1d_setup(direction=direction, flux_bc=flux_bc)
+    odg = oracle.OracleDGModel(law, grid, nf_first=0, direction=direction)
+    dg = cm.dgmodel.DGModel(law, grid, direction=direction)
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    rng = np.random.default_rng(7)
+    Q0 = Q0 + 1e-3 * rng.standard_normal(Q0.shape)     # make every face jump non-trivial
+    T0 = rng.standard_normal(Q0.shape)
+    Q = _gpu(torch, Q0)
+    nr = grid.nreal
+    for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (0.5, 2.0)):
+        To = T0.copy()
+        odg(To, Q0.copy(), 0.3, alpha, beta)
+        Tg = _gpu(torch, T0)
+        dg(Tg, Q, 0.3, alpha, beta)
+        assert rel_linf(Tg.cpu().numpy()[:nr], To[:nr]) < TOL
+        gf = dg.state_gradient_flux.cpu().numpy()[:nr]
+        assert rel_linf(gf, odg.state_gradient_flux[:nr]) < TOL
+        # ghost-free single rank: elements outside realelems untouched
+    dg.close()
+
+
+@pytest.mark.parametrize("direction", [0, 1, 2])
+def test_lsrk_run_matches_golden_and_oracle(cm, oracle, torch, direction):
+    """config 1 of BASELINE.json: 256 LSRK54 steps to t = 1; L2 error against the
+    reference's stored value (rtol 1.5e-8) and the state against the oracle."""
+    law, grid, dt = pseudo1d_setup(direction=direction)
+    dg = cm.dgmodel.DGModel(law, grid, direction=direction)
+    Q = dg.init_ode_state(0.0)
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt, t0=0.0)
+    tend = cm.odesolvers.solve(Q, solver, timeend=1.0)
+    assert tend == 1.0 and solver.steps == 256
+    Qe = dg.init_ode_state(1.0)
+    err = dg.euclidean_distance(Q, Qe)
+    g = GOLD["pseudo1D_advection_diffusion"]
+    exp = g["dim3"][DIRS[direction]][0]
+    assert abs(err - exp) <= g["rtol"] * exp
+    odg = oracle.OracleDGModel(law, grid, nf_first=0, direction=direction)
+    Qo = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    oracle.solve(odg, Qo, dt, 1.0)
+    assert rel_linf(Q.cpu().numpy()[:grid.nreal], Qo[:grid.nreal]) < 1e-11
+    # norm() is the mass-weighted 2-norm (MPIStateArrays.jl:583-604)
+    assert abs(dg.norm(Q) - np.sqrt(oracle.weighted_norm2_local(grid, Qo))) < 1e-12
+    dg.close()
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_local_multirank_matches_single_rank(cm, oracle, torch, size):
+    """The multi-GPU code path (Hilbert partition, interior/exterior split, pack ->
+    transport -> unpack on the second stream) rehearsed on one GPU: `size` handles
+    connected by device copies must reproduce the single-rank tendencies and LSRK
+    states element by element."""
+    law, grid, dt = pseudo1d_setup(direction=0)
+    dg1 = cm.dgmodel.DGModel(law, grid, direction=0)
+    Q1 = dg1.init_ode_state(0.0)
+    T1 = dg1.create_state()
+    torch.cuda.synchronize()
+    dg1(T1, Q1, 0.1, 1.0, 0.0)
+    gl1 = grid.topology.globalelems
+    ref_T = {int(g): T1[i].cpu().numpy() for i, g in enumerate(gl1[:grid.nreal])}
+    dgs, Qs, Ts, grids = [], [], [], []
+    for r in range(size):
+        lawr, gridr, _ = pseudo1d_setup(direction=0, rank=r, size=size)
+        d = cm.dgmodel.DGModel(lawr, gridr, direction=0)
+        dgs.append(d)
+        grids.append(gridr)
+        q = d.init_ode_state(0.0)
+        q[gridr.nreal:] = float("nan")      # ghosts must come from the exchange
+        Qs.append(q)
+        Ts.append(d.create_state())
+    torch.cuda.synchronize()
+    assert sum(g.nreal for g in grids) == grid.nreal
+    cm.dgmodel.connect_local(dgs)
+    cm.dgmodel.group_rhs(dgs, Ts, Qs, 0.1, 1.0, 0.0)
+    for gr, T in zip(grids, Ts):
+        Tn = T.cpu().numpy()
+        for i, g in enumerate(gr.topology.globalelems[:gr.nreal]):
+            assert rel_linf(Tn[i], ref_T[int(g)]) < TOL
+    # a few fused LSRK steps
+    s1 = cm.odesolvers.LSRK54CarpenterKennedy(dg1, Q1, dt=dt)
+    s1.dostep(Q1, nsteps=3)
+    dg1.synchronize()
+    dQs = [d.create_state() for d in dgs]
+    torch.cuda.synchronize()
+    cm.dgmodel.group_lsrk_run(dgs, Qs, dQs, 0.0, dt, 3, s1.RKA, s1.RKB, s1.RKC)
+    for d in dgs:
+        d.synchronize()
+    ref_Q = {int(g): Q1[i].cpu().numpy() for i, g in enumerate(gl1[:grid.nreal])}
+    for gr, q in zip(grids, Qs):
+        qn = q.cpu().numpy()
+        for i, g in enumerate(gr.topology.globalelems[:gr.nreal]):
+            assert rel_linf(qn[i], ref_Q[int(g)]) < TOL
+    for d in dgs + [dg1]:
+        d.close()
+
+
+def test_fails_loudly_without_fallback(cm):
+    """No CPU fallback: a physics / order that is not compiled in is an error."""
+    law, grid, _ = pseudo1d_setup(Ne=2, N=3)
+    with pytest.raises(cm._lib.CmdgError):
+        cm.dgmodel.DGModel(law, grid)
