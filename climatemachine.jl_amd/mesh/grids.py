@@ -341,3 +341,23 @@ class DiscontinuousSpectralElementGrid:
     @property
     def nreal(self):
         return self.topology.nreal
+
+
+def min_node_distance(grid, direction=0):
+    """Minimum physical distance between neighbouring nodes along the reference
+    directions selected by ``direction`` (0 every, 1 horizontal, 2 vertical) over the real
+    elements.  Reference: Grids.jl:444-487, kernel_min_neighbor_distance! :1228-1334.
+    (The reference all-reduces with ``min`` over ranks; this is the local part.)"""
+    d = grid.dim
+    Nq = list(grid.Nq)
+    x = np.stack([grid.vgeo[:grid.nreal, c, :] for c in (_x1, _x2, _x3)], axis=-1)
+    x = x.reshape(grid.nreal, *Nq[::-1], 3)          # (e, k, j, i, 3)
+    use = {0: [True] * d, 1: [True] * (d - 1) + [False], 2: [False] * (d - 1) + [True]}[direction]
+    md = np.inf
+    for ax in range(d):
+        if not use[ax]:
+            continue
+        npax = d - ax                                   # numpy axis of tensor dim ax
+        diff = np.diff(x, axis=npax)
+        md = min(md, float(np.sqrt((diff ** 2).sum(axis=-1)).min()))
+    return md

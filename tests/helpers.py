@@ -24,3 +24,19 @@ def pseudo1d_setup(Ne=4, N=4, direction=0, flux_bc=False, rank=0, size=1, dim=3)
 
 def rel_linf(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def periodic_hyperdiffusion_setup(Ne=4, N=4, direction=0, rank=0, size=1):
+    """test/Numerics/DGMethods/advection_diffusion/periodic_3D_hyperdiffusion.jl:107-322"""
+    from fractions import Fraction as Fr
+    D = np.array([[9, 3, 5], [3, 7, 4], [5, 4, 10]], dtype=np.float64) / 50 / 100
+    x = np.linspace(0.0, 2 * np.pi, Ne + 1)
+    topl = M.StackedBrickTopology([x] * 3, periodicity=(True,) * 3, connectivity="full",
+                                  rank=rank, size=size)
+    grid = M.DiscontinuousSpectralElementGrid(topl, N)
+    law = BL.AdvectionDiffusion(3, BL.ConstantHyperDiffusion(3, direction, D), (),
+                                advection=False, diffusion=False, hyperdiffusion=True)
+    dx = M.grids.min_node_distance(grid)
+    dt = dx ** 4 / 25 / D.sum()
+    dt = 1.0 / np.ceil(1.0 / dt)
+    return law, grid, dt

@@ -134,3 +134,66 @@ def test_fails_loudly_without_fallback(cm):
     law, grid, _ = pseudo1d_setup(Ne=2, N=3)
     with pytest.raises(cm._lib.CmdgError):
         cm.dgmodel.DGModel(law, grid)
+
+
+@pytest.mark.parametrize("direction", [0, 1, 2])
+def test_hyperdiffusion_passes_match_oracle_and_golden(cm, oracle, torch, direction):
+    """periodic_3D_hyperdiffusion.jl: the four extra kernels (volume/interface
+    divergence-of-gradients and gradients-of-laplacians) against the oracle and the
+    reference's stored L2 error."""
+    from helpers import periodic_hyperdiffusion_setup
+    law, grid, dt = periodic_hyperdiffusion_setup(direction=direction)
+    nr = grid.nreal
+    odg = oracle.OracleDGModel(law, grid, nf_first=1, direction=direction)
+    dg = cm.dgmodel.DGModel(law, grid, numerical_flux_first_order=1, direction=direction)
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    Q = _gpu(torch, Q0)
+    To = np.zeros_like(Q0)
+    odg(To, Q0.copy(), 0.0, 1.0, 0.0)
+    Tg = dg.create_state()
+    torch.cuda.synchronize()
+    dg(Tg, Q, 0.0, 1.0, 0.0)
+    assert rel_linf(Tg.cpu().numpy()[:nr], To[:nr]) < TOL
+    assert rel_linf(dg.Qhypervisc_div.cpu().numpy()[:nr, :1], odg.Qhypervisc_div[:nr, :1]) < TOL
+    assert rel_linf(dg.Qhypervisc_grad.cpu().numpy()[:nr], odg.Qhypervisc_grad[:nr]) < TOL
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+    cm.odesolvers.solve(Q, solver, timeend=1.0)
+    err = dg.euclidean_distance(Q, dg.init_ode_state(1.0))
+    g = GOLD["periodic_3D_hyperdiffusion"]
+    exp = g["dim3"][DIRS[direction]][0]
+    assert abs(err - exp) <= g["rtol"] * exp
+    dg.close()
+
+
+def test_local_multirank_hyperdiffusion(cm, oracle, torch):
+    """5 exchanges per RHS (Q, hv-grad, hv-div, hv-grad again) on the overlap stream,
+    3 ranks on one GPU, periodic mesh: must equal the single-rank evaluation."""
+    from helpers import periodic_hyperdiffusion_setup
+    size = 3
+    law, grid, dt = periodic_hyperdiffusion_setup(direction=0)
+    dg1 = cm.dgmodel.DGModel(law, grid, numerical_flux_first_order=1, direction=0)
+    Q1 = dg1.init_ode_state(0.0)
+    s1 = cm.odesolvers.LSRK54CarpenterKennedy(dg1, Q1, dt=dt)
+    s1.dostep(Q1, nsteps=2)
+    dg1.synchronize()
+    ref = {int(g): Q1[i].cpu().numpy() for i, g in
+           enumerate(grid.topology.globalelems[:grid.nreal])}
+    dgs, Qs, grids = [], [], []
+    for r in range(size):
+        lawr, gridr, _ = periodic_hyperdiffusion_setup(direction=0, rank=r, size=size)
+        d = cm.dgmodel.DGModel(lawr, gridr, numerical_flux_first_order=1, direction=0)
+        q = d.init_ode_state(0.0)
+        q[gridr.nreal:] = float("nan")
+        dgs.append(d), Qs.append(q), grids.append(gridr)
+    dQs = [d.create_state() for d in dgs]
+    torch.cuda.synchronize()
+    cm.dgmodel.connect_local(dgs)
+    cm.dgmodel.group_lsrk_run(dgs, Qs, dQs, 0.0, dt, 2, s1.RKA, s1.RKB, s1.RKC)
+    for d in dgs:
+        d.synchronize()
+    for gr, q in zip(grids, Qs):
+        qn = q.cpu().numpy()
+        for i, g in enumerate(gr.topology.globalelems[:gr.nreal]):
+            assert rel_linf(qn[i], ref[int(g)]) < TOL
+    for d in dgs + [dg1]:
+        d.close()

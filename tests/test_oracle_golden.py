@@ -94,3 +94,19 @@ def test_lsrk_coefficients_are_the_rationals(oracle):
         k = A[s] * k + 1.0
         y += B[s] * k
     assert abs(y - 1.0) < 1e-14
+
+
+@pytest.mark.parametrize("direction", [0, 1, 2])
+def test_periodic_hyperdiffusion_level1(oracle, direction):
+    """Pins the hyperdiffusion passes (divergence-of-gradients, gradients-of-laplacians,
+    5 exchanges per RHS) -- periodic_3D_hyperdiffusion.jl:231-249, central fluxes."""
+    from helpers import periodic_hyperdiffusion_setup
+    law, grid, dt = periodic_hyperdiffusion_setup(direction=direction)
+    dg = oracle.OracleDGModel(law, grid, nf_first=1, direction=direction)
+    Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
+    oracle.solve(dg, Q, dt, 1.0)
+    Qe = law.init_state_prognostic(grid, dg.state_auxiliary, 1.0)
+    err = np.sqrt(oracle.weighted_norm2_local(grid, Q, Qe))
+    g = GOLD["periodic_3D_hyperdiffusion"]
+    exp = g["dim3"][DIRS[direction]][0]
+    assert abs(err - exp) <= g["rtol"] * exp, (err, exp)
