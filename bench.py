@@ -47,7 +47,36 @@ def build_workload(cm, name, rank, size, ne, args):
                             "%dx%dx%d brick elements, LSRK54, fp64" % (nx, ne, ne),
                 "elements": nx * ne * ne, "nodes_per_element": 125, "states": law.ns,
                 "parallelism": "element partition (Hilbert), %d rank(s)" % size}
-        return law, grid, 0, dt, desc
+        return law, grid, (0, 0), dt, desc
+    if name == "heldsuarez":
+        # BASELINE.json configs[2]: Held-Suarez dry GCM on the stacked cubed sphere, N = 4,
+        # 8 levels, radii [a, a + 30 km] (experiments/AtmosGCM/heldsuarez.jl:174-240,
+        # src/Driver/driver_configs.jl:344-470).  Weak scaling keeps ~5 400 elements per GPU:
+        # n_horz = 11 / 15 / 21 / 30 at 1 / 2 / 4 / 8 GPUs (6 x 30 x 30 x 8 at 8 GPUs).
+        A = cm.atmos
+        ps = A.PlanetParameters()
+        n_horz = args.nhorz or {1: 11, 2: 15, 3: 18, 4: 21, 5: 24, 6: 26, 7: 28, 8: 30}.get(
+            size, int(round(30 * (size / 8) ** 0.5)))
+        n_vert = args.nvert
+        Rrange = np.linspace(ps.planet_radius, ps.planet_radius + 30e3, n_vert + 1)
+        topl = M.StackedCubedSphereTopology(n_horz, Rrange, boundary=(1, 2), rank=rank, size=size)
+        grid = M.DiscontinuousSpectralElementGrid(topl, 4,
+                                                  meshwarp=M.equiangular_cubed_sphere_warp)
+        law = A.DryAtmosModel(A.HeldSuarezSetup(ps), orientation=A.ORIENT_SPHERICAL,
+                              ref_state=A.DecayingTemperatureProfile(ps, 290.0, 220.0, 8e3),
+                              viscosity=0.0, dynamic_viscosity=False,
+                              hyperdiffusion_timescale=8 * 3600.0,
+                              sources=A.SRC_GRAVITY | A.SRC_CORIOLIS | A.SRC_HELD_SUAREZ,
+                              boundary_conditions=(A.BC_ATMOS_DEFAULT, A.BC_ATMOS_DEFAULT),
+                              param_set=ps)
+        nel = 6 * n_horz * n_horz * n_vert
+        desc = {"workload": "Held-Suarez dry GCM (BASELINE configs[2]), stacked cubed sphere "
+                            "6x%dx%dx%d elements, N=4, LSRK54 explicit, hyperdiffusion "
+                            "(DryBiharmonic, horizontal), Rusanov, fp64" % (n_horz, n_horz, n_vert),
+                "elements": nel, "nodes_per_element": 125, "states": law.ns,
+                "parallelism": "element partition (Hilbert, whole columns), %d rank(s), "
+                               "RCCL p2p halo" % size}
+        return law, grid, (0, 1), 0.15, desc
     raise SystemExit("unknown workload %s" % name)
 
 
@@ -73,7 +102,8 @@ def cpu_baseline(law, grid, direction, dt, budget_s):
     from oracle import oracle as O
     O.build()
     cores = O.get_max_threads()
-    dg = O.OracleDGModel(law, grid, nf_first=0, direction=direction)
+    dg = O.OracleDGModel(law, grid, nf_first=0, direction=direction[0],
+                         diffusion_direction=direction[1])
     Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
     dQ = np.zeros_like(Q)
     O.lsrk54_step(dg, Q, dQ, 0.0, dt)           # warm-up (page faults, thread pool)
@@ -95,8 +125,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="advdiff-brick")
-    ap.add_argument("--ne", type=int, default=32, help="elements per side per rank")
+    ap.add_argument("--workload", default="heldsuarez", choices=["heldsuarez", "advdiff-brick"])
+    ap.add_argument("--ne", type=int, default=32, help="advdiff-brick: elements per side per rank")
+    ap.add_argument("--nhorz", type=int, default=0, help="heldsuarez: elements per cube edge")
+    ap.add_argument("--nvert", type=int, default=8, help="heldsuarez: vertical elements")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -122,7 +154,8 @@ def main():
     law, grid, direction, dt, desc = build_workload(cm, args.workload, rank, world, args.ne, args)
     log("[rank %d] mesh+grid: %d real + %d ghost elements in %.1f s" % (
         rank, grid.nreal, grid.nelem - grid.nreal, time.time() - t0))
-    dg = cm.dgmodel.DGModel(law, grid, direction=direction, device=dev)
+    dg = cm.dgmodel.DGModel(law, grid, direction=direction[0],
+                            diffusion_direction=direction[1], device=dev)
     if world > 1:
         import ctypes as C
         uid = torch.zeros(128, dtype=torch.uint8)

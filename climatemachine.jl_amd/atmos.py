@@ -1,0 +1,269 @@
+"""Host-side description of the dry ``AtmosModel`` configurations carried by libcmdg
+(device functor: ``csrc/physics_atmos.h``).
+
+Reference: ``src/Atmos/Model/AtmosModel.jl`` (vars_state :397-511, gradient argument
+:625-690, wavespeed :808-828), ``tendencies_{mass,momentum,energy}.jl``,
+``atmos_tendencies.jl``, ``energy.jl``, ``moisture.jl:47-62`` (DryModel auxiliary
+``theta_v, air_T`` refreshed every RHS), ``ref_state.jl``, ``boundaryconditions.jl`` +
+``bc_momentum.jl`` + ``bc_energy.jl`` (default ``AtmosBC``: Impenetrable(FreeSlip),
+Insulating), ``src/Common/Orientations/Orientations.jl``,
+``src/Common/TurbulenceClosures/TurbulenceClosures.jl:300-420`` (constant viscosity) and
+``:846-912`` (DryBiharmonic), ``experiments/AtmosGCM/heldsuarez.jl`` (initial condition
+:47-104, forcing :106-172, configuration :174-218),
+``test/Numerics/DGMethods/Euler/isentropicvortex*.jl``.
+
+Thermodynamics.jl 0.3.2 and CLIMAParameters.jl 0.1.11 are registered packages that are
+not vendored in the reference tree; the dry closed forms and planet constants below
+restate their published definitions and are pinned at this boundary by the isentropic
+vortex golden value (``isentropicvortex.jl:105``).
+
+State layout: prognostic ``rho, rho*u(3), rho*e``; auxiliary ``coord(3) [, Phi, grad
+Phi(3)] [, ref rho, p, T, rho*e, rho*q_tot, rho*q_liq, rho*q_ice] [, Delta] , theta_v,
+air_T``; gradient ``u(3), h_tot [, u_h(3), h_tot]``; gradient flux ``grad h_tot(3),
+S(6)``; gradient-laplacian ``u_h(3), h_tot``; hyperdiffusive ``nu grad^3 u_h (9), nu
+grad^3 h_tot (3)``.
+"""
+import numpy as np
+
+from .balancelaws import PHYSICS_DRY_ATMOS
+from .mesh import grids as G
+
+__all__ = ["PlanetParameters", "DryAtmosModel", "IsentropicVortexSetup", "HeldSuarezSetup",
+           "DecayingTemperatureProfile"]
+
+
+class PlanetParameters:
+    """CLIMAParameters.jl 0.1.11 ``Planet`` / ``SubgridScale`` values used by the dry model."""
+    gas_constant = 8.3144598
+    molmass_dryair = 28.97e-3
+    kappa_d = 2 / 7
+    T_0 = 273.16
+    grav = 9.81
+    planet_radius = 6.371e6
+    Omega = 7.2921159e-5
+    MSLP = 1.01325e5
+    day = 86400.0
+    inv_Pr_turb = 3.0
+
+    @property
+    def R_d(self):
+        return self.gas_constant / self.molmass_dryair
+
+    @property
+    def cp_d(self):
+        return self.R_d / self.kappa_d
+
+    @property
+    def cv_d(self):
+        return self.cp_d - self.R_d
+
+
+class DecayingTemperatureProfile:
+    """``DecayingTemperatureProfile(T_virt_surf, T_min_ref, H_t)`` of
+    Thermodynamics.TemperatureProfiles: returns ``(T_virt, p)`` at altitude ``z``."""
+
+    def __init__(self, ps, T_virt_surf=290.0, T_min_ref=220.0, H_t=8e3):
+        self.ps, self.Ts, self.Tm, self.Ht = ps, T_virt_surf, T_min_ref, H_t
+
+    def __call__(self, z):
+        ps = self.ps
+        H_sfc = ps.R_d * self.Ts / ps.grav
+        zp = z / self.Ht
+        th = np.tanh(zp)
+        dTv = self.Ts - self.Tm
+        Tv = self.Ts - dTv * th
+        dTvp = dTv / self.Ts
+        p = -self.Ht * (zp + dTvp * (np.log(1 - dTvp * th) - np.log(1 + th) + zp))
+        p = p / (H_sfc * (1 - dTvp ** 2))
+        p = ps.MSLP * np.exp(p)
+        return Tv, p
+
+
+class IsentropicVortexSetup:
+    """``IsentropicVortexSetup`` (isentropicvortex_setup.jl:3-60)."""
+
+    def __init__(self, ps):
+        self.ps = ps
+        self.p_inf, self.T_inf = 1e5, 300.0
+        self.rho_inf = self.p_inf / (ps.R_d * self.T_inf)
+        self.translation_speed, self.translation_angle = 150.0, np.pi / 4
+        self.vortex_speed, self.vortex_radius = 50.0, 1 / 200
+        self.domain_halflength = 1 / 20
+
+    def __call__(self, law, aux, coord, t):
+        ps = self.ps
+        a = self.translation_angle
+        uinf = np.array([self.translation_speed * np.cos(a), self.translation_speed * np.sin(a), 0.0])
+        L, R = self.domain_halflength, self.vortex_radius
+        x = [coord[d] - uinf[d] * t for d in range(3)]
+        x = [xd - np.floor((xd + L) / (2 * L)) * 2 * L for xd in x]
+        r = np.sqrt(x[0] ** 2 + x[1] ** 2)
+        du_x = -self.vortex_speed * x[1] / R * np.exp(-(r / R) ** 2 / 2)
+        du_y = self.vortex_speed * x[0] / R * np.exp(-(r / R) ** 2 / 2)
+        u = [uinf[0] + du_x, uinf[1] + du_y, uinf[2] + 0 * du_x]
+        T = self.T_inf * (1 - ps.kappa_d * self.vortex_speed ** 2 / 2 * self.rho_inf / self.p_inf
+                          * np.exp(-(r / R) ** 2))
+        p = self.p_inf * (T / self.T_inf) ** (1.0 / ps.kappa_d)
+        rho = p / (ps.R_d * T)
+        e_kin = (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) / 2
+        rhoe = rho * (e_kin + 0.0 + ps.cv_d * (T - ps.T_0))
+        return rho, [rho * u[0], rho * u[1], rho * u[2]], rhoe
+
+
+class HeldSuarezSetup:
+    """``init_heldsuarez!`` (experiments/AtmosGCM/heldsuarez.jl:47-104)."""
+
+    def __init__(self, ps):
+        self.ps = ps
+
+    def __call__(self, law, aux, coord, t):
+        ps = self.ps
+        a = ps.planet_radius
+        z_t, lam_c, phi_c, d_0, V_p = 15e3, np.pi / 9, 2 * np.pi / 9, a / 6, 10.0
+        nrm = np.sqrt(coord[0] ** 2 + coord[1] ** 2 + coord[2] ** 2)
+        phi = np.arcsin(coord[2] / nrm)
+        lam = np.arctan2(coord[1], coord[0])
+        z = aux[:, law.off_phi, :] / ps.grav
+        F_z = 1 - 3 * (z / z_t) ** 2 + 2 * (z / z_t) ** 3
+        F_z = np.where(z > z_t, 0.0, F_z)
+        arg = np.sin(phi) * np.sin(phi_c) + np.cos(phi) * np.cos(phi_c) * np.cos(lam - lam_c)
+        d = a * np.arccos(np.clip(arg, -1.0, 1.0))
+        c3 = np.cos(np.pi * d / 2 / d_0) ** 3
+        s1 = np.sin(np.pi * d / 2 / d_0)
+        ok = (0 < d) & (d < d_0) & (d != a * np.pi)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            up = (-16 * V_p / 3 / np.sqrt(3) * F_z * c3 * s1
+                  * (-np.sin(phi_c) * np.cos(phi) + np.cos(phi_c) * np.sin(phi) * np.cos(lam - lam_c))
+                  / np.sin(d / a))
+            vp = (16 * V_p / 3 / np.sqrt(3) * F_z * c3 * s1 * np.cos(phi_c) * np.sin(lam - lam_c)
+                  / np.sin(d / a))
+        up = np.where(ok, up, 0.0)
+        vp = np.where(ok, vp, 0.0)
+        wp = 0.0 * up
+        sl, cl = np.sin(phi), np.cos(phi)
+        so, co = np.sin(lam), np.cos(lam)
+        u = [-so * up - sl * co * vp + cl * co * wp,
+             co * up - sl * so * vp + cl * so * wp,
+             cl * vp + sl * wp]
+        e_kin = 0.5 * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2])
+        rho = aux[:, law.off_ref + 0, :]
+        rhoe = aux[:, law.off_ref + 3, :] + rho * e_kin
+        return rho, [rho * u[0], rho * u[1], rho * u[2]], rhoe
+
+
+ORIENT_NONE, ORIENT_FLAT, ORIENT_SPHERICAL = 0, 1, 2
+SRC_GRAVITY, SRC_CORIOLIS, SRC_HELD_SUAREZ = 1, 2, 4
+BC_NONE, BC_ATMOS_DEFAULT = 0, 1
+
+
+class DryAtmosModel:
+    """Dry compressible ``AtmosModel``: ``TotalEnergyModel``, ``DryModel``, constant
+    viscosity, optional hydrostatic reference state, ``DryBiharmonic`` hyperdiffusion,
+    sources ``Gravity / Coriolis / HeldSuarezForcing``."""
+    physics_id = PHYSICS_DRY_ATMOS
+
+    def __init__(self, init_state, orientation=ORIENT_SPHERICAL, ref_state=None,
+                 subtract_off=True, viscosity=0.0, dynamic_viscosity=False,
+                 hyperdiffusion_timescale=None, sources=0, boundary_conditions=(),
+                 param_set=None):
+        self.ps = param_set or PlanetParameters()
+        self.init_state = init_state
+        self.orientation = orientation
+        self.ref_state = ref_state
+        self.subtract_off = bool(subtract_off)
+        self.viscosity, self.dynamic_viscosity = float(viscosity), bool(dynamic_viscosity)
+        self.tau_hyper = hyperdiffusion_timescale
+        self.sources = int(sources)
+        self.boundary_conditions = tuple(boundary_conditions)
+        has_or = orientation != ORIENT_NONE
+        has_ref = ref_state is not None
+        has_hyp = hyperdiffusion_timescale is not None
+        o = 3
+        self.off_phi = o
+        o += 4 if has_or else 0
+        self.off_ref = o
+        o += 7 if has_ref else 0
+        self.off_delta = o
+        o += 1 if has_hyp else 0
+        self.off_moist = o
+        o += 2
+        self.ns, self.naux = 5, o
+        self.ngrad = 4 + (4 if has_hyp else 0)
+        self.ngradflux = 9
+        self.ngradlap = 4 if has_hyp else 0
+        self.nhyper = 12 if has_hyp else 0
+
+    def descriptor(self):
+        ps = self.ps
+        ip = np.zeros(16, dtype=np.int32)
+        ip[0] = self.orientation
+        ip[1] = 1 if self.ref_state is not None else 0
+        ip[2] = int(self.subtract_off)
+        ip[3] = 0 if self.dynamic_viscosity else 1
+        ip[4] = 1 if self.tau_hyper is not None else 0
+        ip[5] = self.sources
+        ip[6] = len(self.boundary_conditions)
+        for i, bc in enumerate(self.boundary_conditions):
+            ip[7 + i] = bc
+        dp = np.zeros(32)
+        dp[0] = self.viscosity
+        dp[1] = self.tau_hyper if self.tau_hyper is not None else 0.0
+        dp[2:13] = [ps.R_d, ps.cp_d, ps.cv_d, ps.T_0, ps.grav, ps.Omega, ps.MSLP, ps.day,
+                    ps.planet_radius, ps.inv_Pr_turb, ps.kappa_d]
+        return ip, dp
+
+    # -- init_state_auxiliary! (AtmosModel.jl:880-940) -------------------------------------
+    def init_state_auxiliary(self, grid):
+        ps = self.ps
+        vg = grid.vgeo
+        aux = np.zeros((grid.nelem, self.naux, grid.Np))
+        x = [vg[:, c, :] for c in (G._x1, G._x2, G._x3)]
+        for d in range(3):
+            aux[:, d, :] = x[d]
+        if self.orientation != ORIENT_NONE:
+            if self.orientation == ORIENT_SPHERICAL:     # Orientations.jl:140-150
+                phi = ps.grav * (np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - ps.planet_radius)
+            else:                                         # FlatOrientation
+                phi = ps.grav * x[2]
+            aux[:, self.off_phi, :] = phi
+            # auxiliary_field_gradient!: element-local strong gradient
+            # (dgsem_auxiliary_field_gradient!, DGModel_kernels.jl:3097-3232)
+            Nq = list(grid.Nq)
+            dphi = [G._apply_D(grid.D[b], phi, b, Nq) for b in range(3)]
+            mets = [(G._xi1x1, G._xi1x2, G._xi1x3), (G._xi2x1, G._xi2x2, G._xi2x3),
+                    (G._xi3x1, G._xi3x2, G._xi3x3)]
+            for d in range(3):
+                g = (vg[:, mets[0][d], :] * dphi[0] + vg[:, mets[1][d], :] * dphi[1]) \
+                    + vg[:, mets[2][d], :] * dphi[2]
+                aux[:, self.off_phi + 1 + d, :] = g
+        if self.ref_state is not None:
+            # ref_state_init_p_rho! and ref_state_finalize_init! (ref_state.jl:70-140).  The
+            # reference additionally re-derives rho from a DG gradient of p (discrete
+            # hydrostatic balance, :150-175); the synthetic state here keeps the analytic
+            # rho = p / (R_d T_v) -- documented in DESIGN.md.
+            z = aux[:, self.off_phi, :] / ps.grav
+            Tv, p = self.ref_state(z)
+            rho = p / (Tv * ps.R_d)
+            T = p / (ps.R_d * rho)
+            o = self.off_ref
+            aux[:, o + 0, :] = rho
+            aux[:, o + 1, :] = p
+            aux[:, o + 2, :] = T
+            aux[:, o + 3, :] = rho * (0.0 + aux[:, self.off_phi, :] + ps.cv_d * (T - ps.T_0))
+        if self.tau_hyper is not None:
+            # lengthscale_horizontal (Geometry.jl:129-151): |dx/dxi_1|, |dx/dxi_2|
+            N = grid.N
+            c1 = np.sqrt(vg[:, G._x1xi1] ** 2 + vg[:, G._x2xi1] ** 2 + vg[:, G._x3xi1] ** 2)
+            c2 = np.sqrt(vg[:, G._x1xi2] ** 2 + vg[:, G._x2xi2] ** 2 + vg[:, G._x3xi2] ** 2)
+            aux[:, self.off_delta, :] = (c1 * 2 / N[0] + c2 * 2 / N[1]) / 2
+        return aux
+
+    def init_state_prognostic(self, grid, aux, t):
+        Q = np.zeros((grid.nelem, self.ns, grid.Np))
+        coord = [aux[:, d, :] for d in range(3)]
+        rho, rhou, rhoe = self.init_state(self, aux, coord, t)
+        Q[:, 0, :] = rho
+        for d in range(3):
+            Q[:, 1 + d, :] = rhou[d]
+        Q[:, 4, :] = rhoe
+        return Q

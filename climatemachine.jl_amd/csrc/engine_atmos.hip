@@ -1,11 +1,45 @@
-// Engine instantiations for the dry atmosphere law (placeholder until physics_atmos.h lands).
+// Engine instantiations for the dry atmosphere law (physics_atmos.h).
 #include "engine.h"
+#include "physics_atmos.h"
 
 namespace cmdg {
-int counts_atmos(const int32_t *, int32_t *) { return CMDG_ERR_UNSUPPORTED; }
-EngineBase *make_engine_atmos(const cmdg_desc *, std::string &err)
+
+int counts_atmos(const int32_t *ip, int32_t out[6])
 {
-    err = "dry atmosphere law is not compiled in";
+    const bool orient = ip[0] != 0, ref = ip[1] != 0, hyp = ip[4] != 0;
+    out[0] = 5;
+    out[1] = 3 + (orient ? 4 : 0) + (ref ? 7 : 0) + (hyp ? 1 : 0) + 2;
+    out[2] = 4 + (hyp ? 4 : 0);
+    out[3] = 9;
+    out[4] = hyp ? 4 : 0;
+    out[5] = hyp ? 12 : 0;
+    return CMDG_OK;
+}
+
+template <int NQ>
+static EngineBase *pick(const cmdg_desc *d, std::string &err)
+{
+    const bool orient = d->iparam[0] != 0, ref = d->iparam[1] != 0, hyp = d->iparam[4] != 0;
+    if (!orient && !ref && !hyp) return make_engine<DryAtmos<false, false, false>, NQ>(d);
+    if (orient && ref && hyp) return make_engine<DryAtmos<true, true, true>, NQ>(d);
+    if (orient && ref && !hyp) return make_engine<DryAtmos<true, true, false>, NQ>(d);
+    if (orient && !ref && !hyp) return make_engine<DryAtmos<true, false, false>, NQ>(d);
+    err = "DryAtmos: this orientation/ref-state/hyperdiffusion combination is not compiled in";
     return nullptr;
 }
+
+EngineBase *make_engine_atmos(const cmdg_desc *d, std::string &err)
+{
+    if ((d->iparam[1] != 0 || d->iparam[4] != 0) && d->iparam[0] == 0) {
+        err = "DryAtmos: reference state / hyperdiffusion need an orientation";
+        return nullptr;
+    }
+    switch (d->N[0]) {
+    case 4: return pick<5>(d, err);
+    default:
+        err = "DryAtmos: polynomial order not compiled in (have N = 4)";
+        return nullptr;
+    }
+}
+
 }  // namespace cmdg

@@ -1,0 +1,336 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY (see dg_oracle.h).
+ *
+ * Pointwise physics of the dry AtmosModel configurations in scope, restated from
+ *   src/Atmos/Model/AtmosModel.jl:625-690 (gradient argument), :808-828 (wavespeed)
+ *   src/Atmos/Model/tendencies_mass.jl:5-7, tendencies_momentum.jl:13-29,52-55,62-84,
+ *       tendencies_energy.jl:7-21,37-56      (fluxes and sources, summed in the order of
+ *       atmos_tendencies.jl / BalanceLaws/sum_tendencies.jl)
+ *   src/Atmos/Model/energy.jl:17-28,48-57, moisture.jl:47-62 (DryModel aux update)
+ *   src/Atmos/Model/bc_momentum.jl:25-52, bc_energy.jl:10-20, boundaryconditions.jl:60-100
+ *   src/Common/TurbulenceClosures/TurbulenceClosures.jl:354-420 (constant viscosity),
+ *       :877-912 (DryBiharmonic)
+ *   experiments/AtmosGCM/heldsuarez.jl:106-172 (Held-Suarez forcing)
+ * Thermodynamics.jl 0.3.2 / CLIMAParameters.jl 0.1.11 (not vendored in the reference):
+ * dry closed forms, pinned by test/Numerics/DGMethods/Euler/isentropicvortex.jl:105.
+ *
+ * Parameter block (shared data contract with the product's descriptor):
+ *   iparam[0]=orientation (0 none, 1 flat, 2 spherical) [1]=hydrostatic ref state
+ *   [2]=subtract_off [3]=viscosity kind (0 dynamic rho*nu, 1 kinematic nu)
+ *   [4]=DryBiharmonic [5]=source bits (1 gravity, 2 coriolis, 4 Held-Suarez)
+ *   [6]=nbc [7..13]=bc kind of tag 1..7 (1 = AtmosBC default: Impenetrable(FreeSlip), Insulating)
+ *   dparam[0]=viscosity [1]=tau_hyper [2..12]=R_d cp_d cv_d T_0 grav Omega MSLP day
+ *                                          planet_radius inv_Pr_turb kappa_d
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "dg_oracle.h"
+
+typedef struct {
+    int orient, ref, subtract, kinematic, hyper, src, nbc, bc[8];
+    double visc, tau, R_d, cp_d, cv_d, T_0, grav, Omega, MSLP, day, a, invPr, kappa;
+    int oPhi, oRef, oDelta, oMoist;
+} atmos_t;
+
+/* ---- dry thermodynamics ------------------------------------------------------------ */
+static inline double e_pot_of(const atmos_t *m, const double *aux) { return m->orient ? aux[m->oPhi] : -0.0; }
+static inline double internal_energy(const atmos_t *m, const double *Q, const double *aux)
+{
+    const double rho = Q[0];
+    const double rhoinv = 1 / rho;
+    const double rhoe_kin = rhoinv * (Q[1] * Q[1] + Q[2] * Q[2] + Q[3] * Q[3]) / 2;
+    const double rhoe_pot = rho * e_pot_of(m, aux);
+    const double rhoe_int = Q[4] - rhoe_kin - rhoe_pot;
+    return rhoinv * rhoe_int;
+}
+static inline double air_T(const atmos_t *m, double e_int) { return m->T_0 + e_int / m->cv_d; }
+static inline double air_p(const atmos_t *m, double T, double rho) { return m->R_d * rho * T; }
+static inline double soundspeed(const atmos_t *m, double T)
+{
+    const double gamma = m->cp_d / m->cv_d;
+    return sqrt(gamma * m->R_d * T);
+}
+
+/* ---- first-order fluxes: Mass Advect; Momentum Advect + PressureGradient; Energy Advect + Pressure */
+static void at_flux1(const void *p_, double *F, const double *Q, const double *aux, double t, int dir)
+{
+    const atmos_t *m = (const atmos_t *)p_;
+    (void)t; (void)dir;
+    const double rho = Q[0];
+    const double T = air_T(m, internal_energy(m, Q, aux));
+    const double p = air_p(m, T, rho);
+    double u[3];
+    for (int d = 0; d < 3; ++d) u[d] = Q[1 + d] / rho;
+    for (int d = 0; d < 3; ++d) F[d] = Q[1 + d];
+    const double pp = (m->ref && m->subtract) ? p - aux[m->oRef + 1] : p;
+    for (int c = 0; c < 3; ++c)
+        for (int d = 0; d < 3; ++d)
+            F[d + 3 * (1 + c)] = Q[1 + d] * u[c] + (0.0 + (d == c ? pp : 0.0));
+    for (int d = 0; d < 3; ++d) F[d + 12] = u[d] * Q[4] + u[d] * p;
+}
+
+/* viscosity tensors: nu, D_t, tau = (-2 nu) S  (WithoutDivergence) */
+static void turbulence_tensors(const atmos_t *m, const double *Q, const double *gf, double *nu,
+                               double *Dt, double *tau /*6, compact lower*/)
+{
+    const double v = m->kinematic ? m->visc : m->visc / Q[0];
+    *nu = v;
+    *Dt = v * m->invPr;
+    for (int i = 0; i < 6; ++i) tau[i] = (-2 * v) * gf[3 + i];
+}
+static inline double sym(const double *c, int i, int j)
+{ /* SHermitianCompact{3}: (1,1),(2,1),(3,1),(2,2),(3,2),(3,3) */
+    static const int idx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    return c[idx[i][j]];
+}
+
+static void at_flux2(const void *p_, double *F, const double *Q, const double *gf, const double *hyp,
+                     const double *aux, double t)
+{
+    const atmos_t *m = (const atmos_t *)p_;
+    (void)aux; (void)t;
+    double nu, Dt, tau[6];
+    turbulence_tensors(m, Q, gf, &nu, &Dt, tau);
+    const double rho = Q[0];
+    /* Mass: no second-order tendencies for DryModel -> SVector(0,0,0) */
+    for (int d = 0; d < 3; ++d) F[d] = 0.0;
+    /* Momentum: ViscousStress (pad + tau*rho) [+ HyperdiffViscousFlux rho * nu grad^3 u_h] */
+    for (int c = 0; c < 3; ++c)
+        for (int d = 0; d < 3; ++d) {
+            double v = 0.0 + sym(tau, d, c) * rho;
+            if (m->hyper) v = v + rho * hyp[d + 3 * c];
+            F[d + 3 * (1 + c)] = v;
+        }
+    /* Energy: ViscousFlux tau*rho u, DiffEnthalpyFlux (-D_t grad h_tot) rho
+       [+ HyperdiffEnthalpyFlux nu grad^3 h_tot * rho + HyperdiffViscousFlux nu grad^3 u_h * rho u] */
+    for (int d = 0; d < 3; ++d) {
+        double v = (sym(tau, d, 0) * Q[1] + sym(tau, d, 1) * Q[2] + sym(tau, d, 2) * Q[3]) +
+                   (-Dt * gf[d]) * rho;
+        if (m->hyper) {
+            v = v + hyp[9 + d] * rho;
+            v = v + (hyp[d + 0] * Q[1] + hyp[d + 3] * Q[2] + hyp[d + 6] * Q[3]);
+        }
+        F[d + 12] = v;
+    }
+}
+
+/* Held-Suarez forcing coefficients (heldsuarez.jl:116-155) */
+static void hs_coeffs(const atmos_t *m, const double *Q, const double *aux, double T, double *k_v,
+                      double *k_T, double *T_equil)
+{
+    const double day = m->day;
+    const double k_a = 1 / (40 * day), k_f = 1 / day, k_s = 1 / (4 * day);
+    const double dTy = 60, dthz = 10, T_eq = 315, T_min = 200, sig_b = 7.0 / 10;
+    const double *x = aux;
+    const double phi = asin(x[2] / sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]));
+    const double p = air_p(m, T, Q[0]);
+    const double sig = p / m->MSLP;
+    const double exner = pow(sig, m->R_d / m->cp_d);
+    const double dsig = (sig - sig_b) / (1 - sig_b);
+    const double hf = dsig > 0 ? dsig : 0;
+    const double s = sin(phi), c = cos(phi);
+    double Te = (T_eq - dTy * (s * s) - dthz * log(sig) * (c * c)) * exner;
+    Te = Te > T_min ? Te : T_min;
+    *T_equil = Te;
+    *k_T = k_a + (k_s - k_a) * hf * ((c * c) * (c * c));
+    *k_v = k_f * hf;
+}
+
+static void at_source(const void *p_, double *S, const double *Q, const double *gf, const double *aux,
+                      double t, int dir)
+{
+    const atmos_t *m = (const atmos_t *)p_;
+    (void)gf; (void)t; (void)dir;
+    const double rho = Q[0];
+    double Sm[3] = {0, 0, 0}, Se = 0;
+    int first = 1, firste = 1;
+    double T = 0, k_v = 0, k_T = 0, Te = 0;
+    if (m->src & 4) {
+        T = air_T(m, internal_energy(m, Q, aux));
+        hs_coeffs(m, Q, aux, T, &k_v, &k_T, &Te);
+    }
+    if (m->src & 1) { /* Gravity */
+        const double r = (m->ref && m->subtract) ? rho - aux[m->oRef] : rho;
+        for (int d = 0; d < 3; ++d) {
+            const double v = -r * aux[m->oPhi + 1 + d];
+            Sm[d] = first ? v : Sm[d] + v;
+        }
+        first = 0;
+    }
+    if (m->src & 2) { /* Coriolis: -(0,0,2 Omega) x rho u */
+        const double w = 2 * m->Omega;
+        const double c[3] = {-(0 * Q[3] - w * Q[2]), -(w * Q[1] - 0 * Q[3]), -(0 * Q[2] - 0 * Q[1])};
+        for (int d = 0; d < 3; ++d) Sm[d] = first ? c[d] : Sm[d] + c[d];
+        first = 0;
+    }
+    if (m->src & 4) { /* HeldSuarezForcing */
+        double k[3];
+        for (int d = 0; d < 3; ++d) k[d] = aux[m->oPhi + 1 + d] / m->grav;
+        const double kn = k[0] * Q[1] + k[1] * Q[2] + k[2] * Q[3];
+        for (int d = 0; d < 3; ++d) {
+            const double v = -k_v * (Q[1 + d] - k[d] * kn);
+            Sm[d] = first ? v : Sm[d] + v;
+        }
+        first = 0;
+        const double ve = -k_T * rho * m->cv_d * (T - Te);
+        Se = firste ? ve : Se + ve;
+        firste = 0;
+    }
+    S[0] = 0;
+    S[1] = Sm[0];
+    S[2] = Sm[1];
+    S[3] = Sm[2];
+    S[4] = Se;
+}
+
+static void at_gradarg(const void *p_, double *G, const double *Q, const double *aux, double t)
+{
+    const atmos_t *m = (const atmos_t *)p_;
+    (void)t;
+    const double rhoinv = 1 / Q[0];
+    for (int d = 0; d < 3; ++d) G[d] = rhoinv * Q[1 + d];
+    const double T = air_T(m, internal_energy(m, Q, aux));
+    const double e_tot = Q[4] * (1 / Q[0]);
+    G[3] = e_tot + m->R_d * T;
+    if (m->hyper) {
+        double u[3], k[3];
+        for (int d = 0; d < 3; ++d) u[d] = Q[1 + d] * rhoinv;
+        for (int d = 0; d < 3; ++d) k[d] = aux[m->oPhi + 1 + d] / m->grav;
+        for (int i = 0; i < 3; ++i) { /* (SDiagonal(1,1,1) - k k') * u */
+            double acc = 0;
+            for (int j = 0; j < 3; ++j) {
+                const double Pij = (i == j ? 1.0 : 0.0) - k[i] * k[j];
+                acc = j == 0 ? Pij * u[j] : acc + Pij * u[j];
+            }
+            G[4 + i] = acc;
+        }
+        G[7] = G[3];
+    }
+}
+
+static void at_gradflux(const void *p_, double *gf, const double *g, const double *Q, const double *aux,
+                        double t)
+{
+    (void)p_; (void)Q; (void)aux; (void)t;
+    /* energy: grad h_tot ; turbulence: S = symmetrize(grad u) */
+    for (int d = 0; d < 3; ++d) gf[d] = g[d + 3 * 3];
+    /* grad u is 3x3 with g[d + 3*c] = d u_c / d x_d ; symmetrize(A) = (A + A')/2 lower */
+    gf[3] = g[0 + 3 * 0];
+    gf[4] = (g[1 + 3 * 0] + g[0 + 3 * 1]) / 2;
+    gf[5] = (g[2 + 3 * 0] + g[0 + 3 * 2]) / 2;
+    gf[6] = g[1 + 3 * 1];
+    gf[7] = (g[2 + 3 * 1] + g[1 + 3 * 2]) / 2;
+    gf[8] = g[2 + 3 * 2];
+}
+
+static void at_postlap(const void *p_, double *hyp, const double *gl, const double *Q, const double *aux,
+                       double t)
+{
+    const atmos_t *m = (const atmos_t *)p_;
+    (void)Q; (void)t;
+    if (!m->hyper) return;
+    const double h = aux[m->oDelta] / 2;
+    const double nu4 = (h * h) * (h * h) / 2 / m->tau;
+    for (int q = 0; q < 9; ++q) hyp[q] = nu4 * gl[q];           /* nu grad^3 u_h (3x3) */
+    for (int d = 0; d < 3; ++d) hyp[9 + d] = nu4 * gl[d + 9];    /* nu grad^3 h_tot */
+}
+
+static void at_wavespeed(const void *p_, double *ws, const double *n, const double *Q, const double *aux,
+                         double t, int facedir)
+{
+    const atmos_t *m = (const atmos_t *)p_;
+    (void)t; (void)facedir;
+    const double rhoinv = 1 / Q[0];
+    const double uN = fabs(n[0] * (rhoinv * Q[1]) + n[1] * (rhoinv * Q[2]) + n[2] * (rhoinv * Q[3]));
+    const double ss = soundspeed(m, air_T(m, internal_energy(m, Q, aux)));
+    for (int s = 0; s < 5; ++s) ws[s] = uN + ss;
+}
+
+static void moist_update(const atmos_t *m, const double *Q, double *aux)
+{ /* DryModel atmos_nodal_update_auxiliary_state! (moisture.jl:53-62) */
+    const double T = air_T(m, internal_energy(m, Q, aux));
+    const double p = air_p(m, T, Q[0]);
+    const double exner = pow(p / m->MSLP, m->R_d / m->cp_d);
+    aux[m->oMoist] = m->R_d / m->R_d * (T / exner);
+    aux[m->oMoist + 1] = T;
+}
+
+static void at_bstate(const void *p_, int kind, int bctag, double *QP, double *auxP, const double *n,
+                      const double *QM, const double *auxM, double t, const double *Q1,
+                      const double *aux1)
+{
+    const atmos_t *m = (const atmos_t *)p_;
+    (void)auxM; (void)t; (void)Q1; (void)aux1;
+    if (m->bc[bctag - 1] == 1) {
+        const double dn = QM[1] * n[0] + QM[2] * n[1] + QM[3] * n[2];
+        const double f = kind == ORC_BS_FIRST ? 2 * dn : dn;
+        for (int d = 0; d < 3; ++d) QP[1 + d] -= f * n[d];
+    }
+    moist_update(m, QP, auxP);
+}
+/* normal_boundary_flux_second_order! for AtmosBC (boundaryconditions.jl:101-131): FreeSlip and
+   Insulating add nothing */
+static void at_bflux2(const void *p_, int bctag, double *F, double *QP, double *gfP, double *hypP,
+                      double *auxP, const double *n, const double *QM, const double *gfM,
+                      const double *hypM, const double *auxM, double t, const double *Q1,
+                      const double *gf1, const double *aux1)
+{
+    (void)p_; (void)bctag; (void)F; (void)QP; (void)gfP; (void)hypP; (void)auxP; (void)n; (void)QM;
+    (void)gfM; (void)hypM; (void)auxM; (void)t; (void)Q1; (void)gf1; (void)aux1;
+}
+static void at_bdiv(const void *p_, int bctag, double *gradP, double *auxP, const double *n,
+                    const double *gradM, const double *auxM, double t)
+{
+    (void)p_; (void)bctag; (void)gradP; (void)auxP; (void)n; (void)gradM; (void)auxM; (void)t;
+}
+static void at_bhigher(const void *p_, int bctag, double *QP, double *auxP, double *lapP, const double *n,
+                       const double *QM, const double *auxM, const double *lapM, double t)
+{
+    (void)p_; (void)bctag; (void)QP; (void)auxP; (void)lapP; (void)n; (void)QM; (void)auxM; (void)lapM; (void)t;
+}
+static void at_update_aux(const void *p_, const double *Q, double *aux, double t)
+{
+    (void)t;
+    moist_update((const atmos_t *)p_, Q, aux);
+}
+
+orc_physics *orc_atmos_new(const int *ip, const double *dp, int nf_first)
+{
+    orc_physics *ph = (orc_physics *)calloc(1, sizeof(orc_physics));
+    atmos_t *m = (atmos_t *)calloc(1, sizeof(atmos_t));
+    m->orient = ip[0]; m->ref = ip[1]; m->subtract = ip[2]; m->kinematic = ip[3];
+    m->hyper = ip[4]; m->src = ip[5]; m->nbc = ip[6];
+    for (int i = 0; i < 7; ++i) m->bc[i] = ip[7 + i];
+    m->visc = dp[0]; m->tau = dp[1];
+    m->R_d = dp[2]; m->cp_d = dp[3]; m->cv_d = dp[4]; m->T_0 = dp[5]; m->grav = dp[6];
+    m->Omega = dp[7]; m->MSLP = dp[8]; m->day = dp[9]; m->a = dp[10]; m->invPr = dp[11];
+    m->kappa = dp[12];
+    int o = 3;
+    m->oPhi = o;   o += m->orient ? 4 : 0;
+    m->oRef = o;   o += m->ref ? 7 : 0;
+    m->oDelta = o; o += m->hyper ? 1 : 0;
+    m->oMoist = o; o += 2;
+    ph->ns = 5;
+    ph->naux = o;
+    ph->ngrad = 4 + (m->hyper ? 4 : 0);
+    ph->ngf = 9;
+    ph->ngl = m->hyper ? 4 : 0;
+    ph->nhyp = m->hyper ? 12 : 0;
+    for (int s = 0; s < 4; ++s) ph->hv_indexmap[s] = 4 + s;
+    ph->nf_first = nf_first;
+    ph->p = m;
+    ph->flux_first_order = at_flux1;
+    ph->flux_second_order = at_flux2;
+    ph->source = at_source;
+    ph->gradient_argument = at_gradarg;
+    ph->gradient_flux = at_gradflux;
+    ph->post_gradient_laplacian = at_postlap;
+    ph->wavespeed = at_wavespeed;
+    ph->boundary_state = at_bstate;
+    ph->boundary_flux_second_order = at_bflux2;
+    ph->boundary_state_divergence = at_bdiv;
+    ph->boundary_state_higher_order = at_bhigher;
+    ph->update_aux = at_update_aux;
+    return ph;
+}

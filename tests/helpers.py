@@ -40,3 +40,48 @@ def periodic_hyperdiffusion_setup(Ne=4, N=4, direction=0, rank=0, size=1):
     dt = dx ** 4 / 25 / D.sum()
     dt = 1.0 / np.ceil(1.0 / dt)
     return law, grid, dt
+
+
+def isentropic_vortex_setup(level=1, N=4, rank=0, size=1):
+    """test/Numerics/DGMethods/Euler/isentropicvortex.jl:308-370 (dims = 3, DryModel,
+    NoReferenceState, NoOrientation, ConstantDynamicViscosity(0), periodic BrickTopology)."""
+    A = cm.atmos
+    ps = A.PlanetParameters()
+    setup = A.IsentropicVortexSetup(ps)
+    L = setup.domain_halflength
+    numelems = (2 ** (level - 1) * 5, 2 ** (level - 1) * 5, 1)
+    rng = [np.linspace(-L, L, n + 1) for n in numelems]
+    topl = M.BrickTopology(rng, periodicity=(True,) * 3, connectivity="face", rank=rank, size=size)
+    grid = M.DiscontinuousSpectralElementGrid(topl, N)
+    law = A.DryAtmosModel(setup, orientation=A.ORIENT_NONE, ref_state=None, viscosity=0.0,
+                          dynamic_viscosity=True, sources=0, boundary_conditions=(),
+                          param_set=ps)
+    timeend = 2 * L / 10 / setup.translation_speed
+    elementsize = min(2 * L / n for n in numelems)
+    cs = np.sqrt(ps.cp_d / ps.cv_d * ps.R_d * setup.T_inf)
+    dt = elementsize / cs / N ** 2
+    nsteps = int(np.ceil(timeend / dt))
+    dt = timeend / nsteps
+    return law, grid, dt, timeend, nsteps
+
+
+def held_suarez_setup(n_horz=3, n_vert=2, N=4, rank=0, size=1):
+    """experiments/AtmosGCM/heldsuarez.jl:174-240 with AtmosGCMConfiguration
+    (src/Driver/driver_configs.jl:344-470): stacked cubed sphere, radii [a, a + 30 km],
+    boundary (1, 2), equiangular warp, Rusanov + central fluxes, DryBiharmonic(8 h),
+    ConstantKinematicViscosity(0), sources (Gravity, Coriolis, HeldSuarezForcing),
+    diffusion direction horizontal.  Returns (law, grid, direction, diffusion_direction)."""
+    A = cm.atmos
+    ps = A.PlanetParameters()
+    a, H = ps.planet_radius, 30e3
+    Rrange = np.linspace(a, a + H, n_vert + 1)
+    topl = M.StackedCubedSphereTopology(n_horz, Rrange, boundary=(1, 2), rank=rank, size=size)
+    grid = M.DiscontinuousSpectralElementGrid(topl, N, meshwarp=M.equiangular_cubed_sphere_warp)
+    law = A.DryAtmosModel(A.HeldSuarezSetup(ps), orientation=A.ORIENT_SPHERICAL,
+                          ref_state=A.DecayingTemperatureProfile(ps, 290.0, 220.0, 8e3),
+                          viscosity=0.0, dynamic_viscosity=False,
+                          hyperdiffusion_timescale=8 * 3600.0,
+                          sources=A.SRC_GRAVITY | A.SRC_CORIOLIS | A.SRC_HELD_SUAREZ,
+                          boundary_conditions=(A.BC_ATMOS_DEFAULT, A.BC_ATMOS_DEFAULT),
+                          param_set=ps)
+    return law, grid, 0, 1

@@ -42,13 +42,13 @@ def test_desc_struct_matches_header_field_order():
     txt = open(os.path.join(ROOT, "include", "cmdg.h")).read()
     body = txt[txt.index("typedef struct cmdg_desc {"):txt.index("} cmdg_desc;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    body = body.replace("typedef struct cmdg_desc {", "")
     fields = []
     for stmt in body.split(";"):
-        stmt = stmt.strip()
-        if not stmt or stmt.startswith("typedef"):
+        stmt = " ".join(stmt.split())
+        if not stmt:
             continue
-        decl = stmt.split("\n")[-1] if "{" in stmt else stmt
-        decl = decl.replace("{", "")
+        decl = stmt
         names = re.sub(r"^(const\s+)?\w+\s+", "", decl.strip())
         for nm in names.split(","):
             nm = re.sub(r"\[.*\]", "", nm).replace("*", "").strip()

@@ -197,3 +197,116 @@ def test_local_multirank_hyperdiffusion(cm, oracle, torch):
             assert rel_linf(qn[i], ref[int(g)]) < TOL
     for d in dgs + [dg1]:
         d.close()
+
+
+@pytest.mark.parametrize("nf,name", [(0, "Rusanov"), (1, "Central")])
+def test_isentropic_vortex_gpu(cm, oracle, torch, nf, name):
+    from helpers import isentropic_vortex_setup
+    law, grid, dt, timeend, nsteps = isentropic_vortex_setup()
+    nr = grid.nreal
+    odg = oracle.OracleDGModel(law, grid, nf_first=nf, direction=0)
+    dg = cm.dgmodel.DGModel(law, grid, numerical_flux_first_order=nf, direction=0)
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    To = np.zeros_like(Q0)
+    odg(To, Q0.copy(), 0.0, 1.0, 0.0)
+    Q = _gpu(torch, Q0)
+    Tg = dg.create_state()
+    torch.cuda.synchronize()
+    dg(Tg, Q, 0.0, 1.0, 0.0)
+    Tg = Tg.cpu().numpy()
+    for s in range(5):          # per-state scale (rho*e tendencies are 1e5 x larger)
+        assert rel_linf(Tg[:nr, s], To[:nr, s]) < TOL
+    aux_g = dg.state_auxiliary.cpu().numpy()
+    assert rel_linf(aux_g[:nr, 3:5], odg.state_auxiliary[:nr, 3:5]) < TOL   # theta_v, air_T
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+    cm.odesolvers.solve(Q, solver, timeend=timeend)
+    assert solver.steps == nsteps
+    err = dg.euclidean_distance(Q, dg.init_ode_state(timeend))
+    g = GOLD["isentropicvortex"]
+    exp = g["dim3"][name][0]
+    assert abs(err - exp) <= g["rtol"] * exp
+    dg.close()
+
+
+def _hs_pair(cm, oracle, n_horz=3, n_vert=2, rank=0, size=1):
+    from helpers import held_suarez_setup
+    law, grid, d, dd = held_suarez_setup(n_horz, n_vert, rank=rank, size=size)
+    dg = cm.dgmodel.DGModel(law, grid, direction=d, diffusion_direction=dd)
+    return law, grid, d, dd, dg
+
+
+def test_held_suarez_tendency_matches_oracle(cm, oracle, torch):
+    """The bench workload (BASELINE configs[2]) at a size the oracle finishes in seconds:
+    cubed sphere with orientation flips, hyperdiffusion (5 exchanges), wall BCs, sources.
+    Parity unpinned against the reference for the Held-Suarez script itself (no stored
+    numbers, and the hydrostatic reference density skips the reference's discrete
+    re-balancing step); GPU vs oracle is exact to rounding."""
+    law, grid, d, dd, dg = _hs_pair(cm, oracle)
+    nr = grid.nreal
+    odg = oracle.OracleDGModel(law, grid, nf_first=0, direction=d, diffusion_direction=dd)
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    rng = np.random.default_rng(3)
+    Q0[:, 1:4] += 0.5 * rng.standard_normal(Q0[:, 1:4].shape)     # winds everywhere
+    Q0[:, 4] *= 1 + 1e-3 * rng.standard_normal(Q0[:, 4].shape)
+    To = np.zeros_like(Q0)
+    odg(To, Q0.copy(), 0.0, 1.0, 0.0)
+    Q = _gpu(torch, Q0)
+    Tg = dg.create_state()
+    torch.cuda.synchronize()
+    dg(Tg, Q, 0.0, 1.0, 0.0)
+    Tg = Tg.cpu().numpy()
+    for s in range(5):
+        assert rel_linf(Tg[:nr, s], To[:nr, s]) < 1e-11, s    # cancellation-heavy: see below
+    for name, a, b in (("gf", dg.state_gradient_flux, odg.state_gradient_flux),
+                       ("hvdiv", dg.Qhypervisc_div, odg.Qhypervisc_div),
+                       ("hvgrad", dg.Qhypervisc_grad, odg.Qhypervisc_grad)):
+        a, b = a.cpu().numpy()[:nr], b[:nr]
+        for s in range(b.shape[1]):
+            if np.abs(b[:, s]).max() > 0:
+                assert rel_linf(a[:, s], b[:, s]) < 1e-9, (name, s)
+    # LSRK: 3 fused steps vs the oracle's unfused steps
+    dt = 2.0
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+    solver.dostep(Q, nsteps=3)
+    dg.synchronize()
+    Qo, dQo = Q0.copy(), np.zeros_like(Q0)
+    for s in range(3):
+        oracle.lsrk54_step(odg, Qo, dQo, s * dt, dt)
+    Qg = Q.cpu().numpy()
+    for s in range(5):
+        assert rel_linf(Qg[:nr, s], Qo[:nr, s]) < TOL, s
+    dg.close()
+
+
+def test_held_suarez_local_multirank(cm, oracle, torch):
+    """4 ranks of the cubed sphere on one GPU == 1 rank (orientation-3 faces cross ranks)."""
+    size = 4
+    law, grid, d, dd, dg1 = _hs_pair(cm, oracle)
+    Q1 = dg1.init_ode_state(0.0)
+    s1 = cm.odesolvers.LSRK54CarpenterKennedy(dg1, Q1, dt=2.0)
+    s1.dostep(Q1, nsteps=2)
+    dg1.synchronize()
+    ref = {int(g): Q1[i].cpu().numpy() for i, g in
+           enumerate(grid.topology.globalelems[:grid.nreal])}
+    dgs, Qs, grids = [], [], []
+    for r in range(size):
+        lawr, gridr, _, _, dgr = _hs_pair(cm, oracle, rank=r, size=size)
+        q = dgr.init_ode_state(0.0)
+        q[gridr.nreal:] = float("nan")
+        dgs.append(dgr), Qs.append(q), grids.append(gridr)
+    dQs = [x.create_state() for x in dgs]
+    torch.cuda.synchronize()
+    cm.dgmodel.connect_local(dgs)
+    cm.dgmodel.group_lsrk_run(dgs, Qs, dQs, 0.0, 2.0, 2, s1.RKA, s1.RKB, s1.RKC)
+    for x in dgs:
+        x.synchronize()
+    n = 0
+    for gr, q in zip(grids, Qs):
+        qn = q.cpu().numpy()
+        for i, g in enumerate(gr.topology.globalelems[:gr.nreal]):
+            for s in range(5):
+                assert rel_linf(qn[i, s], ref[int(g)][s]) < TOL
+            n += 1
+    assert n == grid.nreal
+    for x in dgs + [dg1]:
+        x.close()

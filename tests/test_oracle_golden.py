@@ -110,3 +110,20 @@ def test_periodic_hyperdiffusion_level1(oracle, direction):
     g = GOLD["periodic_3D_hyperdiffusion"]
     exp = g["dim3"][DIRS[direction]][0]
     assert abs(err - exp) <= g["rtol"] * exp, (err, exp)
+
+
+@pytest.mark.parametrize("nf,name", [(0, "Rusanov"), (1, "Central")])
+def test_isentropic_vortex_level1(oracle, nf, name):
+    """Dry Euler through the AtmosModel physics (pins the restated Thermodynamics.jl /
+    CLIMAParameters.jl closed forms, Rusanov wavespeed and the 3-D periodic face-connected
+    BrickTopology) -- isentropicvortex.jl:105,109."""
+    from helpers import isentropic_vortex_setup
+    law, grid, dt, timeend, nsteps = isentropic_vortex_setup()
+    dg = oracle.OracleDGModel(law, grid, nf_first=nf, direction=0)
+    Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
+    oracle.solve(dg, Q, dt, timeend)
+    Qe = law.init_state_prognostic(grid, dg.state_auxiliary, timeend)
+    err = np.sqrt(oracle.weighted_norm2_local(grid, Q, Qe))
+    g = GOLD["isentropicvortex"]
+    exp = g["dim3"][name][0]
+    assert abs(err - exp) <= g["rtol"] * exp, (err, exp)
