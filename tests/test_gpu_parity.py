@@ -220,7 +220,7 @@ def test_isentropic_vortex_gpu(cm, oracle, torch, nf, name):
     assert rel_linf(aux_g[:nr, 3:5], odg.state_auxiliary[:nr, 3:5]) < TOL   # theta_v, air_T
     solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
     cm.odesolvers.solve(Q, solver, timeend=timeend)
-    assert solver.steps == nsteps
+    assert solver.steps in (nsteps, nsteps + 1)   # t += dt may leave a last sliver step, as in solve!
     err = dg.euclidean_distance(Q, dg.init_ode_state(timeend))
     g = GOLD["isentropicvortex"]
     exp = g["dim3"][name][0]
