@@ -157,16 +157,13 @@ def main():
     dg = cm.dgmodel.DGModel(law, grid, direction=direction[0],
                             diffusion_direction=direction[1], device=dev)
     if world > 1:
-        import ctypes as C
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
-            buf = (C.c_char * 128)()
-            cm._lib.check(cm._lib.lib().cmdg_comm_unique_id(C.cast(buf, C.c_void_p)))
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            uid = torch.frombuffer(bytearray(cm.dgmodel.rccl_unique_id()), dtype=torch.uint8).clone()
         uid = uid.to(dev)
         dist.broadcast(uid, 0)
-        raw = bytes(uid.cpu().numpy().tobytes())
-        cm._lib.check(cm._lib.lib().cmdg_comm_init_rccl(dg.handle, raw, rank, world), dg.handle)
+        dg.comm_init_rccl(uid.cpu().numpy().tobytes(), rank, world)
+        dg.comm_selftest()
     Q = dg.init_ode_state(0.0)
     solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
 

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcmdg.so")
+LIB_PATH = os.environ.get("CMDG_LIB", os.path.join(_HERE, "libcmdg.so"))   # CMDG_LIB: tuning builds
 
 CMDG_K = dict(GRADIENTS=0, DIVGRAD=1, GRADLAP=2, TENDENCY=3, PACK=4, UNPACK=5, UPDATE_AUX=6)
 
@@ -52,6 +52,7 @@ SYMBOLS = [
     ("cmdg_halo_end", C.c_int, [_vp, _vp, _i32]),
     ("cmdg_comm_unique_id", C.c_int, [_vp]),
     ("cmdg_comm_init_rccl", C.c_int, [_vp, _vp, _i32, _i32]),
+    ("cmdg_comm_selftest", C.c_int, [_vp, _i64]),
     ("cmdg_comm_connect_local", C.c_int, [_vp, _i32]),
     ("cmdg_group_rhs", C.c_int, [_vp, _i32, _vp, _vp, _d, _d, _d]),
     ("cmdg_group_lsrk_run", C.c_int, [_vp, _i32, _vp, _vp, _d, _d, _i64, _i32, _vp, _vp, _vp]),

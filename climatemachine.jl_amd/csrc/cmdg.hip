@@ -79,6 +79,7 @@ EngineBase::~EngineBase()
     if (W[0]) hipFree(W[0]);
     if (W[1]) hipFree(W[1]);
     if (d_D) hipFree(d_D);
+    if (derived) hipFree(derived);
     if (d_partial) hipFree(d_partial);
     if (ev_comp) hipEventDestroy(ev_comp);
     if (nccl_comm && rccl::CommDestroy) rccl::CommDestroy(nccl_comm);
@@ -172,7 +173,7 @@ int EngineBase::init(const cmdg_desc *d)
         }
     }
     HIPCHK(hipMalloc(&d_partial, sizeof(double) * 1024));
-    return CMDG_OK;
+    return init_derived();
 }
 
 int EngineBase::ensure_work()
@@ -324,7 +325,7 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
     if ((r = (x)) != CMDG_OK) return r
     switch (seg) {
     case 0:
-        launch_update_aux(c, 0, nreal);
+        if (!(grad && fused_update_aux())) launch_update_aux(c, 0, nreal);
         if (comm) TRY(halo_begin(SLOT_Q, c.Qin, ns));
         if (grad) launch_gradients(c, d_interior, ninterior);
         break;
@@ -641,6 +642,38 @@ int cmdg_comm_init_rccl(cmdg_handle h, const void *unique_id128, int32_t rank, i
     e->rank = rank;
     e->nranks = nranks;
     return CMDG_OK;
+}
+
+int cmdg_comm_selftest(cmdg_handle h, int64_t count)
+{
+    if (!h || count < 1) return CMDG_ERR_INVALID;
+    EngineBase *e = h->eng;
+    if (e->transport != TRANSPORT_RCCL || !e->nccl_comm)
+        return set_err(h, e->fail(CMDG_ERR_COMM, "selftest: RCCL transport not initialised"));
+    double *src = nullptr, *dst = nullptr;
+    std::vector<double> host((size_t)count), back((size_t)count, -1.0);
+    for (int64_t i = 0; i < count; ++i) host[i] = 0.5 * (double)i + 1e-3 * e->rank;
+    int rc = CMDG_OK;
+    if (hipMalloc(&src, sizeof(double) * count) != hipSuccess ||
+        hipMalloc(&dst, sizeof(double) * count) != hipSuccess)
+        rc = e->fail(CMDG_ERR_HIP, "selftest: hipMalloc failed");
+    if (!rc && hipMemcpy(src, host.data(), sizeof(double) * count, hipMemcpyHostToDevice) != hipSuccess)
+        rc = e->fail(CMDG_ERR_HIP, "selftest: upload failed");
+    if (!rc) {
+        int n = rccl::GroupStart();
+        if (!n) n = rccl::Recv(dst, (size_t)count, rccl::kDouble, e->rank, e->nccl_comm, e->s_comm);
+        if (!n) n = rccl::Send(src, (size_t)count, rccl::kDouble, e->rank, e->nccl_comm, e->s_comm);
+        int g = rccl::GroupEnd();
+        if (n || g) rc = e->fail(CMDG_ERR_COMM, std::string("selftest: ") + rccl::GetErrorString(n ? n : g));
+    }
+    if (!rc && hipStreamSynchronize(e->s_comm) != hipSuccess) rc = e->fail(CMDG_ERR_HIP, "selftest: sync failed");
+    if (!rc && hipMemcpy(back.data(), dst, sizeof(double) * count, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = e->fail(CMDG_ERR_HIP, "selftest: download failed");
+    if (!rc && memcmp(back.data(), host.data(), sizeof(double) * count) != 0)
+        rc = e->fail(CMDG_ERR_COMM, "selftest: payload mismatch");
+    if (src) hipFree(src);
+    if (dst) hipFree(dst);
+    return set_err(h, rc);
 }
 
 int cmdg_comm_connect_local(cmdg_handle *handles, int32_t n)

@@ -56,6 +56,7 @@ struct EngineBase {
     std::vector<int> nabrtorank;
     std::vector<int64_t> nabrsend, nabrrecv;  // 2*nnabr (first,last) 1-based
     double *aux = nullptr, *gf = nullptr, *hypgrad = nullptr, *hypdiv = nullptr;
+    double *derived = nullptr;  // (Np, NDER, nelem), library-owned
     bool own_gf = false, own_hg = false, own_hd = false;
     // ---- runtime -----------------------------------------------------------------------
     hipStream_t s_comp = nullptr, s_comm = nullptr;
@@ -90,6 +91,8 @@ struct EngineBase {
     virtual void launch_tendency(const RhsCtx &c, const int64_t *elems, int64_t n) = 0;
     virtual void launch_update_aux(const RhsCtx &c, int64_t e0, int64_t e1) = 0;
     virtual bool has_update_aux() const = 0;
+    virtual bool fused_update_aux() const = 0;
+    virtual int init_derived() = 0;
 
     // orchestration
     static constexpr int NSEG = 5;
@@ -126,6 +129,8 @@ struct EngineT : EngineBase {
         a.nelems = n;
         a.Q = c.Qin;
         a.aux = aux;
+        a.aux_rw = aux;
+        a.derived = derived;
         a.gf = gf;
         a.hypgrad = hypgrad;
         a.hypdiv = hypdiv;
@@ -189,6 +194,20 @@ struct EngineT : EngineBase {
         }
     }
     bool has_update_aux() const override { return P::HAS_UPDATE_AUX; }
+    bool fused_update_aux() const override { return P::HAS_UPDATE_AUX && P::FUSE_UPDATE_AUX; }
+    int init_derived() override
+    {
+        if constexpr (P::NDER > 0) {
+            const int64_t n = nelem * KDims<NQ_>::Np;
+            if (hipMalloc(&derived, sizeof(double) * n * P::NDER) != hipSuccess)
+                return fail(CMDG_ERR_HIP, "hipMalloc(derived) failed");
+            hipLaunchKernelGGL((k_init_derived<P, NQ_>), dim3((unsigned)((n + 255) / 256)), dim3(256),
+                               0, s_comp, prm, aux, derived, nelem);
+            if (hipStreamSynchronize(s_comp) != hipSuccess)
+                return fail(CMDG_ERR_HIP, "k_init_derived failed");
+        }
+        return CMDG_OK;
+    }
 };
 
 template <class P, int NQ_>

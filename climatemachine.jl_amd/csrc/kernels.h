@@ -15,6 +15,17 @@
 #pragma once
 #include "cmdg_common.h"
 
+// minimum waves per SIMD requested from the register allocator (tuning knobs)
+#ifndef CMDG_TEND_MINW
+#define CMDG_TEND_MINW 1
+#endif
+#ifndef CMDG_GRAD_MINW
+#define CMDG_GRAD_MINW 1
+#endif
+#ifndef CMDG_LAP_MINW
+#define CMDG_LAP_MINW 1
+#endif
+
 namespace cmdg {
 
 // ---------------------------------------------------------------------------------
@@ -27,6 +38,8 @@ struct PassArgs {
     // state arrays
     const double *Q;
     const double *aux;
+    double *aux_rw;         // same array, for the fused auxiliary refresh
+    const double *derived;  // handle-owned time-invariant per-node fields of the law (P::NDER)
     double *gf;        // state_gradient_flux (written by gradients, read by tendency)
     double *hypgrad;   // Qhypervisc_grad
     double *hypdiv;    // Qhypervisc_div
@@ -100,17 +113,42 @@ __device__ __forceinline__ void nf_first_order(const typename P::Params &prm, in
 }
 
 // ---------------------------------------------------------------------------------
+// Index of a surface node among the element's surface nodes (-1: interior node).  The
+// minus-side face data of the interface phases is staged in LDS for surface nodes only.
+template <int NQ>
+__device__ __forceinline__ int surf_index(int ijk)
+{
+    constexpr int NI = NQ - 2;
+    const int i = ijk % NQ, j = (ijk / NQ) % NQ, k = ijk / (NQ * NQ);
+    const bool ii = i >= 1 && i <= NI, jj = j >= 1 && j <= NI, kk = k >= 1 && k <= NI;
+    if (ii && jj && kk) return -1;
+    auto clampi = [](int v) { return v < 0 ? 0 : (v > NI ? NI : v); };
+    int before = NI * NI * clampi(k - 1);
+    if (kk) {
+        before += NI * clampi(j - 1);
+        if (jj) before += clampi(i - 1);
+    }
+    return ijk - before;
+}
+template <int NQ>
+struct SurfDims {
+    static constexpr int NSURF = NQ * NQ * NQ - (NQ - 2) * (NQ - 2) * (NQ - 2);
+};
+
+// ---------------------------------------------------------------------------------
 // Tendency pass: volume_tendency! (:64-548) + dgsem_interface_tendency! (:588-901),
 // optionally fused with the LSRK update! (LowStorageRungeKuttaMethod.jl:146-158).
 template <class P, int NQ, bool LSRK>
-__global__ void __launch_bounds__(KDims<NQ>::NT) k_tendency(const PassArgs<P> a)
+__global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(const PassArgs<P> a)
 {
     using KD = KDims<NQ>;
     constexpr int Np = KD::Np, Nfp = KD::Nfp, NS = P::NS, NAUX = P::NAUX, NGF = P::NGF,
-                  NHYP = P::NHYP, NHG = 3 * P::NGL;
+                  NHYP = P::NHYP, NHG = 3 * P::NGL, NFA = P::NFAUX,
+                  NSURF = SurfDims<NQ>::NSURF, NMF = NS + NFA + NGF + NHYP;
     __shared__ double sD[NQ * NQ];
-    __shared__ double sF[3 * NS * Np];  // contravariant flux [d][s][ijk]
-    __shared__ double sT[NS * Np];      // tendency accumulator [s][ijk]
+    __shared__ double sF[3 * NS * Np];  // contravariant flux [d][s][ijk]; later the accumulator
+    __shared__ double sM[NMF * NSURF];  // minus-side state of the surface nodes [field][sidx]
+    double *const sT = sF;              // tendency accumulator [s][ijk] (aliases sF after phase 2)
     const int tid = threadIdx.x;
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
     if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
@@ -131,6 +169,17 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_tendency(const PassArgs<P> a)
 #pragma unroll
         for (int s = 0; s < NHYP; ++s)
             lhyp[s] = a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)];
+        const int sidx = surf_index<NQ>(tid);
+        if (sidx >= 0) {  // stage the minus side of the interface phase
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sM[s * NSURF + sidx] = lQ[s];
+#pragma unroll
+            for (int s = 0; s < NFA; ++s) sM[(NS + s) * NSURF + sidx] = laux[P::face_aux(s)];
+#pragma unroll
+            for (int s = 0; s < NGF; ++s) sM[(NS + NFA + s) * NSURF + sidx] = lgf[s];
+#pragma unroll
+            for (int s = 0; s < NHYP; ++s) sM[(NS + NFA + NGF + s) * NSURF + sidx] = lhyp[s];
+        }
         Vec<3 * NS> F, F2;
         F.negzero();
         P::flux_first_order(a.prm, F, lQ, laux, a.t, a.model_dir);
@@ -157,9 +206,16 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_tendency(const PassArgs<P> a)
             }
         }
         S.negzero();
-        if constexpr (P::HAS_SOURCE) P::source(a.prm, S, lQ, lgf, laux, a.t, a.model_dir);
+#ifndef CMDG_DBG_NOSRC
+        if constexpr (P::HAS_SOURCE) {
+            Vec<P::NDER> lder;
+            load_state<P::NDER, Np>(lder, a.derived, tid, e);
+            P::source(a.prm, S, lQ, lgf, laux, lder, a.t, a.model_dir);
+        }
+#endif
     }
     __syncthreads();
+    Vec<NS> Tv;
     if (tid < Np) {
         const int i = tid % NQ, j = (tid / NQ) % NQ, k = tid / (NQ * NQ);
 #pragma unroll
@@ -190,14 +246,22 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_tendency(const PassArgs<P> a)
                 else
                     T = a.beta != 0 ? a.alpha * lt + a.beta * Told : a.alpha * lt;
             }
-            sT[s * Np + tid] = T;
+            Tv[s] = T;
         }
     }
-    __syncthreads();
+    __syncthreads();  // every read of sF is done: it becomes the accumulator sT
+    if (tid < Np) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sT[s * Np + tid] = Tv[s];
+    }
     // ---- faces: dgsem_interface_tendency! ------------------------------------------
     Vec<NS> lift;
     int vidM = 0, fpair = -1;
+#ifdef CMDG_DBG_NOFACE
+    if (false) {
+#else
     if (tid < KD::NFT) {
+#endif
         const int f = tid / Nfp, n = tid % Nfp;
         const bool on = f < 4 ? hz : vt;
         if (on) {
@@ -208,17 +272,28 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_tendency(const PassArgs<P> a)
             Vec<NAUX> auxM, auxPn, auxPd;
             Vec<NGF> gfM, gfP;
             Vec<NHYP> hypM, hypP;
-            load_state<NS, Np>(QM, a.Q, fp.vidM, e);
-            load_state<NAUX, Np>(auxM, a.aux, fp.vidM, e);
-            load_state<NGF, Np>(gfM, a.gf, fp.vidM, e);
+            const int sidx = surf_index<NQ>(fp.vidM);
+#pragma unroll
+            for (int s = 0; s < NAUX; ++s) auxM[s] = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) QM[s] = sM[s * NSURF + sidx];
+#pragma unroll
+            for (int s = 0; s < NFA; ++s) auxM[P::face_aux(s)] = sM[(NS + s) * NSURF + sidx];
+#pragma unroll
+            for (int s = 0; s < NGF; ++s) gfM[s] = sM[(NS + NFA + s) * NSURF + sidx];
+#pragma unroll
+            for (int s = 0; s < NHYP; ++s) hypM[s] = sM[(NS + NFA + NGF + s) * NSURF + sidx];
             load_state<NS, Np>(QPn, a.Q, fp.vidP, fp.eP);
-            load_state<NAUX, Np>(auxPn, a.aux, fp.vidP, fp.eP);
+#pragma unroll
+            for (int s = 0; s < NAUX; ++s) auxPn[s] = 0;
+#pragma unroll
+            for (int s = 0; s < NFA; ++s)
+                auxPn[P::face_aux(s)] =
+                    a.aux[fp.vidP + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * fp.eP)];
             load_state<NGF, Np>(gfP, a.gf, fp.vidP, fp.eP);
 #pragma unroll
-            for (int s = 0; s < NHYP; ++s) {
-                hypM[s] = a.hypgrad[fp.vidM + (int64_t)Np * (s + (int64_t)NHG * e)];
+            for (int s = 0; s < NHYP; ++s)
                 hypP[s] = a.hypgrad[fp.vidP + (int64_t)Np * (s + (int64_t)NHG * fp.eP)];
-            }
 #pragma unroll
             for (int s = 0; s < NS; ++s) QPd[s] = QPn[s];
 #pragma unroll
@@ -240,6 +315,11 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_tendency(const PassArgs<P> a)
                                (FM[3 * s + 1] + FP[3 * s + 1]) * nh1 +
                                (FM[3 * s + 2] + FP[3 * s + 2]) * nh2;
             } else {
+                // boundary: the plus side is a copy of the minus side (e+ = e-, :686-692)
+                // and the full minus-side auxiliary state may be needed by the law
+                load_state<NAUX, Np>(auxM, a.aux, fp.vidM, e);
+#pragma unroll
+                for (int s = 0; s < NAUX; ++s) auxPn[s] = auxPd[s] = auxM[s];
                 Vec<NS> Q1;
                 Vec<NAUX> aux1;
                 Vec<NGF> gf1;
@@ -272,6 +352,7 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_tendency(const PassArgs<P> a)
             fpair = f / 2;
         }
     }
+    __syncthreads();
 #pragma unroll
     for (int p = 0; p < 3; ++p) {  // opposite faces touch disjoint nodes (:898-899)
         if (fpair == p) {
@@ -298,7 +379,7 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_tendency(const PassArgs<P> a)
 // ---------------------------------------------------------------------------------
 // Gradient pass: volume_gradients! (:934-1328) + dgsem_interface_gradients! (:1365-1651)
 template <class P, int NQ>
-__global__ void __launch_bounds__(KDims<NQ>::NT) k_gradients(const PassArgs<P> a)
+__global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_GRAD_MINW) k_gradients(const PassArgs<P> a)
 {
     using KD = KDims<NQ>;
     constexpr int Np = KD::Np, Nfp = KD::Nfp, NS = P::NS, NAUX = P::NAUX, NGRAD = P::NGRAD,
@@ -315,6 +396,15 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_gradients(const PassArgs<P> a
     if (tid < Np) {
         load_state<NS, Np>(lQ, a.Q, tid, e);
         load_state<NAUX, Np>(laux, a.aux, tid, e);
+        if constexpr (P::HAS_UPDATE_AUX && P::FUSE_UPDATE_AUX) {
+            // kernel_nodal_update_auxiliary_state! of the real elements, fused: the refreshed
+            // entries are read by no kernel of this evaluation (see P::FUSE_UPDATE_AUX)
+            P::update_aux(a.prm, lQ, laux, a.t);
+#pragma unroll
+            for (int s = 0; s < P::NUPD; ++s)
+                a.aux_rw[tid + (int64_t)Np * (P::upd_aux(s) + (int64_t)NAUX * e)] =
+                    laux[P::upd_aux(s)];
+        }
         Vec<NGRAD> G;
         G.negzero();
         P::gradient_argument(a.prm, G, lQ, laux, a.t);
@@ -573,7 +663,7 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_divgrad(const PassArgs<P> a)
 // Gradient-of-Laplacian pass: volume_gradients_of_laplacians! (:2525-2824) +
 // interface_gradients_of_laplacians! (:2859-3026)
 template <class P, int NQ>
-__global__ void __launch_bounds__(KDims<NQ>::NT) k_gradlap(const PassArgs<P> a)
+__global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_LAP_MINW) k_gradlap(const PassArgs<P> a)
 {
     using KD = KDims<NQ>;
     constexpr int Np = KD::Np, Nfp = KD::Nfp, NS = P::NS, NAUX = P::NAUX, NGL = P::NGL,
@@ -715,6 +805,24 @@ __global__ void k_update_aux(typename P::Params prm, const double *Q, double *au
     P::update_aux(prm, lQ, laux, t);
 #pragma unroll
     for (int s = 0; s < NAUX; ++s) aux[n + (int64_t)Np * (s + (int64_t)NAUX * e)] = laux[s];
+}
+
+// one-time: time-invariant per-node fields the law would otherwise recompute every call
+template <class P, int NQ>
+__global__ void k_init_derived(typename P::Params prm, const double *aux, double *derived,
+                               int64_t nelem)
+{
+    constexpr int Np = KDims<NQ>::Np, NAUX = P::NAUX, NDER = P::NDER;
+    const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e = I / Np;
+    const int n = (int)(I % Np);
+    if (e >= nelem) return;
+    Vec<NAUX> laux;
+    load_state<NAUX, Np>(laux, aux, n, e);
+    Vec<NDER> d;
+    P::init_derived(prm, d, laux);
+#pragma unroll
+    for (int s = 0; s < NDER; ++s) derived[n + (int64_t)Np * (s + (int64_t)NDER * e)] = d[s];
 }
 
 // ---------------------------------------------------------------------------------

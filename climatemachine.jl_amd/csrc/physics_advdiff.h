@@ -33,7 +33,14 @@ struct AdvDiff {
     static constexpr int NHYP = HYPER ? 3 : 0;
     static constexpr int OU = 3, OD = 3 + (ADV ? 3 : 0), OH = OD + (DIFF ? 9 : 0);
     static constexpr bool HAS_UPDATE_AUX = false;
+    static constexpr bool FUSE_UPDATE_AUX = false;
+    static constexpr int NUPD = 0;
+    __host__ __device__ static constexpr int upd_aux(int) { return 0; }
     static constexpr bool HAS_SOURCE = false;
+    static constexpr int NDER = 0;
+    // auxiliary fields the interface kernels need from the minus side (all of them)
+    static constexpr int NFAUX = NAUX;
+    __host__ __device__ static constexpr int face_aux(int i) { return i; }
     __host__ __device__ static constexpr int hv_indexmap(int) { return 0; }
 
     static constexpr int BC_INHOM(int o) { return 1 << o; }
@@ -112,9 +119,10 @@ struct AdvDiff {
             for (int d = 0; d < 3; ++d) F[d] += hyp[d];
     }
     __device__ static void source(const Params &, double *, const double *, const double *,
-                                  const double *, double, int)
+                                  const double *, const double *, double, int)
     {
     }
+    __device__ static void init_derived(const Params &, double *, const double *) {}
     __device__ static void gradient_argument(const Params &, double *G, const double *Q,
                                              const double *, double)
     {

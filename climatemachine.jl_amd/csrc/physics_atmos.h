@@ -39,8 +39,23 @@ struct DryAtmos {
     static constexpr int NGL = HYPER ? 4 : 0;
     static constexpr int NHYP = HYPER ? 12 : 0;
     static constexpr bool HAS_UPDATE_AUX = true;
+    // the refresh only writes moisture.theta_v / air_T, which no dry tendency reads, so it
+    // can ride in the gradient kernel's first phase instead of costing a pass of its own
+    static constexpr bool FUSE_UPDATE_AUX = true;
+    static constexpr int NUPD = 2;
+    __host__ __device__ static constexpr int upd_aux(int i) { return OMOIST + i; }
     static constexpr bool HAS_SOURCE = true;
+    // sin / cos of the latitude (heldsuarez.jl:134,147-149 recomputes them every call; they
+    // only depend on aux.coord, so they are evaluated once with the same libm calls)
+    static constexpr int NDER = ORIENT ? 2 : 0;
     __host__ __device__ static constexpr int hv_indexmap(int s) { return 4 + s; }
+    // auxiliary fields the interior-face fluxes read from the minus side: Phi (potential
+    // energy in the thermodynamic state) and the reference pressure
+    static constexpr int NFAUX = (ORIENT ? 1 : 0) + (REF ? 1 : 0);
+    __host__ __device__ static constexpr int face_aux(int i)
+    {
+        return ORIENT ? (i == 0 ? OPHI : OREF + 1) : OREF + 1;
+    }
 
     static void make_params(Params &p, const int32_t *ip, const double *dp)
     {
@@ -142,19 +157,27 @@ struct DryAtmos {
         }
     }
     // Held-Suarez forcing coefficients (heldsuarez.jl:116-155)
-    __device__ static void hs_coeffs(const Params &m, const double *Q, const double *aux,
+    __device__ static void init_derived(const Params &, double *der, const double *aux)
+    {
+        if constexpr (ORIENT) {
+            const double phi =
+                asin(aux[2] / sqrt(aux[0] * aux[0] + aux[1] * aux[1] + aux[2] * aux[2]));
+            der[0] = sin(phi);
+            der[1] = cos(phi);
+        }
+    }
+    __device__ static void hs_coeffs(const Params &m, const double *Q, const double *der,
                                      double T, double &k_v, double &k_T, double &T_equil)
     {
         const double day = m.day;
         const double k_a = 1 / (40 * day), k_f = 1 / day, k_s = 1 / (4 * day);
         const double dTy = 60, dthz = 10, T_eq = 315, T_min = 200, sig_b = 7.0 / 10;
-        const double phi = asin(aux[2] / sqrt(aux[0] * aux[0] + aux[1] * aux[1] + aux[2] * aux[2]));
         const double p = air_p(m, T, Q[0]);
         const double sig = p / m.MSLP;
         const double exner = pow(sig, m.R_d / m.cp_d);
         const double dsig = (sig - sig_b) / (1 - sig_b);
         const double hf = dsig > 0 ? dsig : 0;
-        const double s = sin(phi), c = cos(phi);
+        const double s = der[0], c = der[1];
         double Te = (T_eq - dTy * (s * s) - dthz * log(sig) * (c * c)) * exner;
         Te = Te > T_min ? Te : T_min;
         T_equil = Te;
@@ -162,7 +185,7 @@ struct DryAtmos {
         k_v = k_f * hf;
     }
     __device__ static void source(const Params &m, double *S, const double *Q, const double *,
-                                  const double *aux, double, int)
+                                  const double *aux, const double *der, double, int)
     {
         const double rho = Q[0];
         double Sm[3] = {0, 0, 0}, Se = 0;
@@ -170,7 +193,7 @@ struct DryAtmos {
         double T = 0, k_v = 0, k_T = 0, Te = 0;
         if (m.src & 4) {
             T = air_T(m, internal_energy(m, Q, aux));
-            hs_coeffs(m, Q, aux, T, k_v, k_T, Te);
+            hs_coeffs(m, Q, der, T, k_v, k_T, Te);
         }
         if constexpr (ORIENT) {
             if (m.src & 1) {  // Gravity

@@ -19,7 +19,7 @@ import torch
 from . import _lib
 from .balancelaws import EveryDirection, RusanovNumericalFlux
 
-__all__ = ["DGModel", "connect_local", "group_rhs", "group_lsrk_run"]
+__all__ = ["DGModel", "connect_local", "group_rhs", "group_lsrk_run", "rccl_unique_id"]
 
 
 def _dev(a, device, dtype=None):
@@ -163,6 +163,15 @@ class DGModel:
             len(rka), C.cast(a, C.c_void_p), C.cast(b, C.c_void_p), C.cast(c, C.c_void_p)),
             self.handle)
 
+    # -- transport --------------------------------------------------------------------
+    def comm_init_rccl(self, unique_id, rank, nranks):
+        """``unique_id``: the 128 bytes of ``rccl_unique_id()`` made on rank 0."""
+        _lib.check(self.L.cmdg_comm_init_rccl(self.handle, bytes(unique_id), int(rank),
+                                              int(nranks)), self.handle)
+
+    def comm_selftest(self, count=4096):
+        _lib.check(self.L.cmdg_comm_selftest(self.handle, int(count)), self.handle)
+
     # -- reductions (local part) ------------------------------------------------------
     def norm2_local(self, A, weighted=True):
         out = C.c_double()
@@ -198,6 +207,12 @@ class DGModel:
                                            C.cast(C.byref(ms), C.c_void_p),
                                            C.cast(C.byref(n), C.c_void_p)), self.handle)
         return ms.value, n.value
+
+
+def rccl_unique_id():
+    buf = (C.c_char * 128)()
+    _lib.check(_lib.lib().cmdg_comm_unique_id(C.cast(buf, C.c_void_p)))
+    return bytes(buf.raw)
 
 
 def _harr(dgs):

@@ -130,6 +130,10 @@ int cmdg_halo_end(cmdg_handle h, double *array, int32_t nstate);
  * ncclUniqueId made by cmdg_comm_unique_id on rank 0 and broadcast by the caller. */
 int cmdg_comm_unique_id(void *out128);
 int cmdg_comm_init_rccl(cmdg_handle h, const void *unique_id128, int32_t rank, int32_t nranks);
+/* Transport self-check: sends `count` doubles to this rank itself with the same
+ * ncclGroupStart / ncclRecv / ncclSend / ncclGroupEnd sequence the halo uses, on the halo
+ * stream, and verifies the payload.  Needs cmdg_comm_init_rccl first (nranks may be 1). */
+int cmdg_comm_selftest(cmdg_handle h, int64_t count);
 /* Single-process: connect n handles (handle r plays rank r) through device copies. */
 int cmdg_comm_connect_local(cmdg_handle *handles, int32_t n);
 

@@ -310,3 +310,17 @@ def test_held_suarez_local_multirank(cm, oracle, torch):
     assert n == grid.nreal
     for x in dgs + [dg1]:
         x.close()
+
+
+def test_rccl_transport_selftest(cm, torch):
+    """The RCCL transport itself (dlopen of librccl, ncclCommInitRank with the by-value
+    unique id, grouped ncclRecv/ncclSend of doubles on the halo stream) on a 1-rank
+    communicator: the only part of the multi-GPU path the single-GPU box cannot run with
+    real neighbours."""
+    law, grid, _ = pseudo1d_setup()
+    dg = cm.dgmodel.DGModel(law, grid)
+    uid = cm.dgmodel.rccl_unique_id()
+    assert len(uid) == 128
+    dg.comm_init_rccl(uid, 0, 1)
+    dg.comm_selftest(12345)
+    dg.close()
