@@ -145,7 +145,10 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
-    if world > 1:
+    # launched by torch.distributed.run (even with one rank): take the distributed path, so
+    # that a 1-rank launch rehearses process-group + RCCL set-up on a single-GPU box
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device(dev))
@@ -156,7 +159,7 @@ def main():
         rank, grid.nreal, grid.nelem - grid.nreal, time.time() - t0))
     dg = cm.dgmodel.DGModel(law, grid, direction=direction[0],
                             diffusion_direction=direction[1], device=dev)
-    if world > 1:
+    if distributed:
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             uid = torch.frombuffer(bytearray(cm.dgmodel.rccl_unique_id()), dtype=torch.uint8).clone()
@@ -170,7 +173,7 @@ def main():
     def sync_all():
         dg.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
 
     solver.dostep(Q, nsteps=args.warmup)
@@ -184,7 +187,7 @@ def main():
     dg.synchronize()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         dist.barrier()
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -228,10 +231,10 @@ def main():
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(law, grid, direction, dt, args.cpu_budget)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    dg.close()
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
-    dg.close()
 
 
 if __name__ == "__main__":

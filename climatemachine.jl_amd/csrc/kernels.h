@@ -58,6 +58,39 @@ struct FacePt {
     int vidM, vidP, bctag;
 };
 
+// index half of face_setup: issued at kernel start so that the plus-side gathers do not wait
+// for a dependent table load when the interface phase begins
+template <int NQ>
+__device__ __forceinline__ void face_index(const GridDev &g, int64_t e, int f, int n, int64_t &idM,
+                                           int64_t &idP, int &bctag)
+{
+    constexpr int Nfp = KDims<NQ>::Nfp;
+    const int64_t o = n + (int64_t)Nfp * (f + 6 * e);
+    idM = g.vmapM[o];
+    idP = g.vmapP[o];
+    bctag = (int)g.elemtobndy[f + 6 * e];
+}
+template <int NQ>
+__device__ __forceinline__ void face_geometry(const GridDev &g, int64_t e, int f, int n,
+                                              int64_t idM, int64_t idP, int bctag, FacePt &fp)
+{
+    constexpr int Np = KDims<NQ>::Np, Nfp = KDims<NQ>::Nfp;
+    const int64_t o = n + (int64_t)Nfp * (f + 6 * e);
+    const double *sg = g.sgeo + 5 * o;
+    fp.n[0] = sg[SN1];
+    fp.n[1] = sg[SN2];
+    fp.n[2] = sg[SN3];
+    fp.sM = sg[SSM];
+    fp.vMI = sg[SVMI];
+    fp.bctag = bctag;
+    fp.eP = (idP - 1) / Np;
+    fp.vidM = (int)((idM - 1) % Np);
+    fp.vidP = (int)((idP - 1) % Np);
+    if (bctag != 0) {  // DGModel_kernels.jl:686-692
+        fp.eP = e;
+        fp.vidP = fp.vidM;
+    }
+}
 template <int NQ>
 __device__ __forceinline__ void face_setup(const GridDev &g, int64_t e, int f, int n, FacePt &fp)
 {
@@ -153,6 +186,10 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
     if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
     const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
+    int64_t f_idM = 1, f_idP = 1;
+    int f_bctag = 0;
+    const bool face_on = tid < KD::NFT && ((tid / Nfp) < 4 ? hz : vt);
+    if (face_on) face_index<NQ>(a.g, e, tid / Nfp, tid % Nfp, f_idM, f_idP, f_bctag);
     Vec<NS> S;
     double MI = 0;
     if (tid < Np) {
@@ -263,11 +300,10 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
     if (tid < KD::NFT) {
 #endif
         const int f = tid / Nfp, n = tid % Nfp;
-        const bool on = f < 4 ? hz : vt;
-        if (on) {
+        if (face_on) {
             const int facedir = f < 4 ? DIR_HORIZONTAL : DIR_VERTICAL;
             FacePt fp;
-            face_setup<NQ>(a.g, e, f, n, fp);
+            face_geometry<NQ>(a.g, e, f, n, f_idM, f_idP, f_bctag, fp);
             Vec<NS> QM, QPn, QPd, flux;
             Vec<NAUX> auxM, auxPn, auxPd;
             Vec<NGF> gfM, gfP;
@@ -481,10 +517,10 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_GRAD_MINW) k_gradients(con
             Vec<NS> QM, QP;
             Vec<NAUX> auxM, auxP;
             Vec<NGRAD> GM, GP;
-            load_state<NS, Np>(QM, a.Q, fp.vidM, e);
-            load_state<NAUX, Np>(auxM, a.aux, fp.vidM, e);
-            GM.negzero();
-            P::gradient_argument(a.prm, GM, QM, auxM, a.t);
+            load_state<NS, Np>(QM, a.Q, fp.vidM, e);       // only kept if the law reads them
+            load_state<NAUX, Np>(auxM, a.aux, fp.vidM, e);  // (gradient_flux / boundary_state)
+#pragma unroll
+            for (int s = 0; s < NGRAD; ++s) GM[s] = sG[s * Np + fp.vidM];  // == G(Q-, aux-)
             load_state<NS, Np>(QP, a.Q, fp.vidP, fp.eP);
             load_state<NAUX, Np>(auxP, a.aux, fp.vidP, fp.eP);
             GP.negzero();
@@ -567,6 +603,8 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_divgrad(const PassArgs<P> a)
     __shared__ double sD[NQ * NQ];
     __shared__ double sC[3 * NG * Np];  // M * (xi_d . grad) [d][s][ijk]
     __shared__ double sA[NG * Np];
+    constexpr int NSURF = SurfDims<NQ>::NSURF;
+    __shared__ double sM[(NHG > 0 ? NHG : 1) * NSURF];  // minus-side gradients, surface nodes
     const int tid = threadIdx.x;
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
     if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
@@ -587,6 +625,12 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_divgrad(const PassArgs<P> a)
             sC[(0 * NG + s) * Np + tid] = M * (x11 * G1 + x12 * G2 + x13 * G3);
             sC[(1 * NG + s) * Np + tid] = M * (x21 * G1 + x22 * G2 + x23 * G3);
             sC[(2 * NG + s) * Np + tid] = M * (x31 * G1 + x32 * G2 + x33 * G3);
+            const int sidx = surf_index<NQ>(tid);
+            if (sidx >= 0) {
+                sM[(3 * s + 0) * NSURF + sidx] = G1;
+                sM[(3 * s + 1) * NSURF + sidx] = G2;
+                sM[(3 * s + 2) * NSURF + sidx] = G3;
+            }
         }
     }
     __syncthreads();
@@ -620,9 +664,10 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_divgrad(const PassArgs<P> a)
             FacePt fp;
             face_setup<NQ>(a.g, e, f, n, fp);
             Vec<NHG> gM, gP;
+            const int sidx = surf_index<NQ>(fp.vidM);
 #pragma unroll
             for (int q = 0; q < NHG; ++q) {
-                gM[q] = a.hypgrad[fp.vidM + (int64_t)Np * (q + (int64_t)NHG * e)];
+                gM[q] = sM[q * NSURF + sidx];
                 gP[q] = a.hypgrad[fp.vidP + (int64_t)Np * (q + (int64_t)NHG * fp.eP)];
             }
             if (fp.bctag != 0) {  // numerical_boundary_flux_divergence!  :732-763
@@ -750,7 +795,7 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_LAP_MINW) k_gradlap(const 
             load_state<NAUX, Np>(auxP, a.aux, fp.vidP, fp.eP);
 #pragma unroll
             for (int s = 0; s < NGL; ++s) {
-                lapM[s] = a.hypdiv[fp.vidM + (int64_t)Np * (s + (int64_t)NHYP * e)];
+                lapM[s] = sL[s * Np + fp.vidM];
                 lapP[s] = a.hypdiv[fp.vidP + (int64_t)Np * (s + (int64_t)NHYP * fp.eP)];
             }
             if (fp.bctag != 0)  // numerical_boundary_flux_higher_order!  :792-832
