@@ -174,12 +174,24 @@ struct EngineT : EngineBase {
     {
         if (n <= 0) return;
         prof_begin(CMDG_K_TENDENCY, s_comp);
-        if (c.lsrk)
-            hipLaunchKernelGGL((k_tendency<P, NQ_, true>), dim3((unsigned)n),
-                               dim3(KDims<NQ_>::NT), 0, s_comp, make_args(c, elems, n, direction));
-        else
-            hipLaunchKernelGGL((k_tendency<P, NQ_, false>), dim3((unsigned)n),
-                               dim3(KDims<NQ_>::NT), 0, s_comp, make_args(c, elems, n, direction));
+#ifdef CMDG_GF_ALWAYS
+        const bool gfl = true;
+#else
+        const bool gfl = P::needs_gradflux(prm);
+#endif
+        const dim3 grid((unsigned)n), block(KDims<NQ_>::NT);
+        const PassArgs<P> args = make_args(c, elems, n, direction);
+        if (c.lsrk) {
+            if (gfl)
+                hipLaunchKernelGGL((k_tendency<P, NQ_, true, true>), grid, block, 0, s_comp, args);
+            else
+                hipLaunchKernelGGL((k_tendency<P, NQ_, true, false>), grid, block, 0, s_comp, args);
+        } else {
+            if (gfl)
+                hipLaunchKernelGGL((k_tendency<P, NQ_, false, true>), grid, block, 0, s_comp, args);
+            else
+                hipLaunchKernelGGL((k_tendency<P, NQ_, false, false>), grid, block, 0, s_comp, args);
+        }
         prof_end(s_comp);
     }
     void launch_update_aux(const RhsCtx &c, int64_t e0, int64_t e1) override

@@ -171,13 +171,14 @@ struct SurfDims {
 // ---------------------------------------------------------------------------------
 // Tendency pass: volume_tendency! (:64-548) + dgsem_interface_tendency! (:588-901),
 // optionally fused with the LSRK update! (LowStorageRungeKuttaMethod.jl:146-158).
-template <class P, int NQ, bool LSRK>
+template <class P, int NQ, bool LSRK, bool USE_GF>
 __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(const PassArgs<P> a)
 {
     using KD = KDims<NQ>;
     constexpr int Np = KD::Np, Nfp = KD::Nfp, NS = P::NS, NAUX = P::NAUX, NGF = P::NGF,
                   NHYP = P::NHYP, NHG = 3 * P::NGL, NFA = P::NFAUX,
-                  NSURF = SurfDims<NQ>::NSURF, NMF = NS + NFA + NGF + NHYP;
+                  NSURF = SurfDims<NQ>::NSURF, NGFS = USE_GF ? NGF : 0,
+                  NMF = NS + NFA + NGFS + NHYP;
     __shared__ double sD[NQ * NQ];
     __shared__ double sF[3 * NS * Np];  // contravariant flux [d][s][ijk]; later the accumulator
     __shared__ double sM[NMF * NSURF];  // minus-side state of the surface nodes [field][sidx]
@@ -186,6 +187,10 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
     if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
     const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
+    // USE_GF: does flux_second_order depend on the gradient-flux state at all?  With zero
+    // viscosity (Held-Suarez) tau = -2*0*S and D_t = 0: the 9 fields only ever multiply
+    // zeros, so the host picks the instantiation that does not read them (identical results).
+    constexpr bool use_gf = NGF > 0 && USE_GF;
     int64_t f_idM = 1, f_idP = 1;
     int f_bctag = 0;
     const bool face_on = tid < KD::NFT && ((tid / Nfp) < 4 ? hz : vt);
@@ -202,7 +207,9 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
         Vec<NHYP> lhyp;
         load_state<NS, Np>(lQ, a.Q, tid, e);
         load_state<NAUX, Np>(laux, a.aux, tid, e);
-        load_state<NGF, Np>(lgf, a.gf, tid, e);
+#pragma unroll
+        for (int s = 0; s < NGF; ++s) lgf[s] = 0.0;
+        if (use_gf) load_state<NGF, Np>(lgf, a.gf, tid, e);
 #pragma unroll
         for (int s = 0; s < NHYP; ++s)
             lhyp[s] = a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)];
@@ -212,10 +219,12 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
             for (int s = 0; s < NS; ++s) sM[s * NSURF + sidx] = lQ[s];
 #pragma unroll
             for (int s = 0; s < NFA; ++s) sM[(NS + s) * NSURF + sidx] = laux[P::face_aux(s)];
+            if (use_gf) {
 #pragma unroll
-            for (int s = 0; s < NGF; ++s) sM[(NS + NFA + s) * NSURF + sidx] = lgf[s];
+                for (int s = 0; s < NGF; ++s) sM[(NS + NFA + s) * NSURF + sidx] = lgf[s];
+            }
 #pragma unroll
-            for (int s = 0; s < NHYP; ++s) sM[(NS + NFA + NGF + s) * NSURF + sidx] = lhyp[s];
+            for (int s = 0; s < NHYP; ++s) sM[(NS + NFA + NGFS + s) * NSURF + sidx] = lhyp[s];
         }
         Vec<3 * NS> F, F2;
         F.negzero();
@@ -316,9 +325,14 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
 #pragma unroll
             for (int s = 0; s < NFA; ++s) auxM[P::face_aux(s)] = sM[(NS + s) * NSURF + sidx];
 #pragma unroll
-            for (int s = 0; s < NGF; ++s) gfM[s] = sM[(NS + NFA + s) * NSURF + sidx];
+            for (int s = 0; s < NGF; ++s) gfM[s] = gfP[s] = 0.0;
+            if (use_gf) {
 #pragma unroll
-            for (int s = 0; s < NHYP; ++s) hypM[s] = sM[(NS + NFA + NGF + s) * NSURF + sidx];
+                for (int s = 0; s < NGF; ++s) gfM[s] = sM[(NS + NFA + s) * NSURF + sidx];
+                load_state<NGF, Np>(gfP, a.gf, fp.vidP, fp.eP);
+            }
+#pragma unroll
+            for (int s = 0; s < NHYP; ++s) hypM[s] = sM[(NS + NFA + NGFS + s) * NSURF + sidx];
             load_state<NS, Np>(QPn, a.Q, fp.vidP, fp.eP);
 #pragma unroll
             for (int s = 0; s < NAUX; ++s) auxPn[s] = 0;
@@ -326,7 +340,6 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
             for (int s = 0; s < NFA; ++s)
                 auxPn[P::face_aux(s)] =
                     a.aux[fp.vidP + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * fp.eP)];
-            load_state<NGF, Np>(gfP, a.gf, fp.vidP, fp.eP);
 #pragma unroll
             for (int s = 0; s < NHYP; ++s)
                 hypP[s] = a.hypgrad[fp.vidP + (int64_t)Np * (s + (int64_t)NHG * fp.eP)];
@@ -365,7 +378,7 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
                 if (f == 4) {  // bottom face: first interior node (:786-816)
                     load_state<NS, Np>(Q1, a.Q, n + NQ * NQ, e);
                     load_state<NAUX, Np>(aux1, a.aux, n + NQ * NQ, e);
-                    load_state<NGF, Np>(gf1, a.gf, n + NQ * NQ, e);
+                    if (use_gf) load_state<NGF, Np>(gf1, a.gf, n + NQ * NQ, e);
                 }
                 // numerical_boundary_flux_first_order!  NumericalFluxes.jl:163-205
                 P::boundary_state(a.prm, BS_FIRST, fp.bctag, QPn, auxPn, fp.n, QM, auxM, a.t, Q1,

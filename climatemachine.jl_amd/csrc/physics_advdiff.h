@@ -38,6 +38,7 @@ struct AdvDiff {
     __host__ __device__ static constexpr int upd_aux(int) { return 0; }
     static constexpr bool HAS_SOURCE = false;
     static constexpr int NDER = 0;
+    __host__ __device__ static bool needs_gradflux(const Params &) { return DIFF; }
     // auxiliary fields the interface kernels need from the minus side (all of them)
     static constexpr int NFAUX = NAUX;
     __host__ __device__ static constexpr int face_aux(int i) { return i; }

@@ -49,6 +49,8 @@ struct DryAtmos {
     // only depend on aux.coord, so they are evaluated once with the same libm calls)
     static constexpr int NDER = ORIENT ? 2 : 0;
     __host__ __device__ static constexpr int hv_indexmap(int s) { return 4 + s; }
+    // tau = (-2 nu) S and D_t = nu / Pr: with nu == 0 the gradient-flux state only multiplies zeros
+    __host__ __device__ static bool needs_gradflux(const Params &m) { return m.visc != 0; }
     // auxiliary fields the interior-face fluxes read from the minus side: Phi (potential
     // energy in the thermodynamic state) and the reference pressure
     static constexpr int NFAUX = (ORIENT ? 1 : 0) + (REF ? 1 : 0);

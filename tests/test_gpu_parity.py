@@ -324,3 +324,97 @@ def test_rccl_transport_selftest(cm, torch):
     dg.comm_init_rccl(uid, 0, 1)
     dg.comm_selftest(12345)
     dg.close()
+
+
+# ---------------------------------------------------------------------------------------
+# Size-independent properties at BASELINE.json's full sizes (the oracle is too slow there)
+# ---------------------------------------------------------------------------------------
+def _hs_full(cm, n_horz, n_vert=8, rank=0, size=1):
+    from helpers import held_suarez_setup
+    law, grid, d, dd = held_suarez_setup(n_horz, n_vert, rank=rank, size=size)
+    dg = cm.dgmodel.DGModel(law, grid, direction=d, diffusion_direction=dd)
+    return law, grid, dg
+
+
+def test_full_size_held_suarez_properties(cm, torch):
+    """configs[2] at its full size, 6 x 30 x 30 x 8 = 43 200 elements on one GPU:
+    (1) determinism: two evaluations are bit identical; (2) alpha-linearity: alpha = 2 doubles
+    every entry exactly; (3) beta-accumulation; (4) mass conservation: sum_e sum_n M * drho/dt
+    vanishes (free-slip walls, closed sphere) relative to sum M |drho/dt|."""
+    law, grid, dg = _hs_full(cm, 30)
+    assert grid.nreal == 43200
+    Q = dg.init_ode_state(0.0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Q[:, 1:4] += 2.0 * torch.randn(Q[:, 1:4].shape, generator=g, device="cuda", dtype=torch.float64)
+    T1, T2, T3 = dg.create_state(), dg.create_state(), dg.create_state()
+    torch.cuda.synchronize()
+    dg(T1, Q, 0.0, 1.0, 0.0)
+    dg(T2, Q, 0.0, 1.0, 0.0)
+    assert torch.equal(T1, T2)
+    dg(T2, Q, 0.0, 2.0, 0.0)
+    assert torch.equal(T2, 2.0 * T1)
+    T3.copy_(T1)
+    torch.cuda.synchronize()
+    dg(T3, Q, 0.0, 1.0, 1.0)             # T3 = rhs + T1 = 2 rhs up to one rounding per entry
+    scale = T1.abs().amax(dim=(0, 2), keepdim=True)
+    assert ((T3 - 2.0 * T1).abs() / scale).max().item() < 1e-14
+    M = dg._vgeo[:grid.nreal, 9, :]
+    drho = T1[:grid.nreal, 0, :]
+    total = (M * drho).sum().item()
+    ref = (M * drho.abs()).sum().item()
+    assert abs(total) < 1e-10 * ref, (total, ref)
+    assert torch.isfinite(T1).all()
+    dg.close()
+
+
+def test_full_size_multirank_equals_single_rank(cm, torch):
+    """The 8-GPU decomposition of the 43 200-element sphere (5 400 elements per rank, the
+    scaling run's geometry) rehearsed on one GPU with the local transport: 2 fused LSRK54
+    steps agree with the undecomposed run entry for entry."""
+    size = 8
+    law, grid, dg1 = _hs_full(cm, 30)
+    Q1 = dg1.init_ode_state(0.0)
+    s1 = cm.odesolvers.LSRK54CarpenterKennedy(dg1, Q1, dt=0.15)
+    s1.dostep(Q1, nsteps=2)
+    dg1.synchronize()
+    gl = torch.from_numpy(np.asarray(grid.topology.globalelems[:grid.nreal]) - 1).cuda()
+    ref = torch.empty_like(Q1[:grid.nreal])
+    ref[gl] = Q1[:grid.nreal]
+    dgs, Qs, grids = [], [], []
+    for r in range(size):
+        lawr, gridr, dgr = _hs_full(cm, 30, rank=r, size=size)
+        q = dgr.init_ode_state(0.0)
+        q[gridr.nreal:] = float("nan")
+        dgs.append(dgr), Qs.append(q), grids.append(gridr)
+    assert sum(g.nreal for g in grids) == grid.nreal
+    assert all(g.nreal == 5400 for g in grids)
+    dQs = [x.create_state() for x in dgs]
+    torch.cuda.synchronize()
+    cm.dgmodel.connect_local(dgs)
+    cm.dgmodel.group_lsrk_run(dgs, Qs, dQs, 0.0, 0.15, 2, s1.RKA, s1.RKB, s1.RKC)
+    for x in dgs:
+        x.synchronize()
+    scale = ref.abs().amax(dim=(0, 2), keepdim=True)
+    for gr, q in zip(grids, Qs):
+        idx = torch.from_numpy(np.asarray(gr.topology.globalelems[:gr.nreal]) - 1).cuda()
+        err = ((q[:gr.nreal] - ref[idx]).abs() / scale).max().item()
+        assert err < TOL, err
+    for x in dgs + [dg1]:
+        x.close()
+
+
+def test_config1_parity_at_4096_elements(cm, oracle, torch):
+    """configs[0] physics at 16^3 elements (512 000 nodes): exact tendency parity with the
+    oracle at a size where every CU holds several workgroups."""
+    law, grid, _ = pseudo1d_setup(Ne=16, direction=0)
+    odg = oracle.OracleDGModel(law, grid, nf_first=0, direction=0)
+    dg = cm.dgmodel.DGModel(law, grid, direction=0)
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    To = np.zeros_like(Q0)
+    odg(To, Q0.copy(), 0.2, 1.0, 0.0)
+    Q = _gpu(torch, Q0)
+    Tg = dg.create_state()
+    torch.cuda.synchronize()
+    dg(Tg, Q, 0.2, 1.0, 0.0)
+    assert rel_linf(Tg.cpu().numpy()[:grid.nreal], To[:grid.nreal]) < TOL
+    dg.close()
