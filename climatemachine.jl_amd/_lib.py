@@ -8,7 +8,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMDG_LIB", os.path.join(_HERE, "libcmdg.so"))   # CMDG_LIB: tuning builds
 
-CMDG_K = dict(GRADIENTS=0, DIVGRAD=1, GRADLAP=2, TENDENCY=3, PACK=4, UNPACK=5, UPDATE_AUX=6)
+CMDG_K = dict(GRADIENTS=0, DIVGRAD=1, GRADLAP=2, TENDENCY=3, PACK=4, UNPACK=5, UPDATE_AUX=6,
+              FILTER=7)
 
 
 class CmdgDesc(C.Structure):
@@ -58,6 +59,10 @@ SYMBOLS = [
     ("cmdg_group_lsrk_run", C.c_int, [_vp, _i32, _vp, _vp, _d, _d, _i64, _i32, _vp, _vp, _vp]),
     ("cmdg_norm2_local", C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     ("cmdg_distance2_local", C.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    ("cmdg_filter_create", C.c_int, [_vp, _vp, C.POINTER(_vp)]),
+    ("cmdg_filter_destroy", C.c_int, [_vp, _vp]),
+    ("cmdg_filter_apply", C.c_int, [_vp, _vp, _vp, _i32]),
+    ("cmdg_set_filters", C.c_int, [_vp, _vp, _vp, _vp]),
     ("cmdg_profile_enable", C.c_int, [_vp, _i32]),
     ("cmdg_profile_get", C.c_int, [_vp, _i32, _vp, _vp]),
     ("cmdg_profile_reset", C.c_int, [_vp]),

@@ -7,6 +7,7 @@
 #include <new>
 
 #include "engine.h"
+#include "filters.h"
 
 namespace cmdg {
 
@@ -336,6 +337,7 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
             launch_update_aux(c, nreal, nelem);
         }
         launch_gradients(c, d_exterior, nexterior);
+        if (gradient_filter && ngf > 0) TRY(filter_apply(gradient_filter, gf, ngf));  // (:185-193)
         if (comm) {
             if (ngf > 0) TRY(halo_begin(SLOT_GF, gf, ngf));
             if (hyper) TRY(halo_begin(SLOT_HG, hypgrad, 3 * ngl));
@@ -368,6 +370,12 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
             }
         }
         launch_tendency(c, d_exterior, nexterior);
+        if (tendency_filter) TRY(filter_apply(tendency_filter, c.tendency, ns));  // (:417-425)
+        if (c.update_after) {
+            const int64_t n = (int64_t)Np * ns * nreal;
+            hipLaunchKernelGGL(k_lsrk_update, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)),
+                               dim3(256), 0, s_comp, c.tendency, c.Qin, c.rka_next, c.rkb_dt, n);
+        }
         break;
     default: break;
     }
@@ -423,25 +431,155 @@ int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, doubl
     for (int s = 0; s < nstages; ++s) {
         for (size_t i = 0; i < g.size(); ++i) {
             RhsCtx &x = c[i];
-            lsrk_stage_buffers(g[i], Q[i], s, nstages, &x.Qin, &x.Qout);
-            if (nstages == 1) x.Qout = g[i]->W[0];
+            // a tendency filter acts on dQ between rhs! and update!: no fused update then
+            const bool fused = g[i]->tendency_filter == nullptr;
+            if (fused) {
+                lsrk_stage_buffers(g[i], Q[i], s, nstages, &x.Qin, &x.Qout);
+                if (nstages == 1) x.Qout = g[i]->W[0];
+            } else {
+                x.Qin = Q[i];
+                x.Qout = nullptr;
+            }
             x.tendency = dQ[i];
             x.t = t + rkc[s] * dt;
             x.alpha = 1.0;  // rhs!(dQ, Q, p, time + RKC[s] * dt, increment = true)
             x.beta = 1.0;
-            x.lsrk = true;
+            x.lsrk = fused;
+            x.update_after = !fused;
             x.rkb_dt = rkb[s] * dt;
             x.rka_next = rka[(s + 1) % nstages];
         }
         if (int r = group_rhs(g, c)) return r;
     }
-    if (nstages == 1)
-        for (size_t i = 0; i < g.size(); ++i) {
-            EngineBase *e = g[i];
+    for (size_t i = 0; i < g.size(); ++i) {
+        EngineBase *e = g[i];
+        if (nstages == 1 && e->tendency_filter == nullptr)
             if (hipMemcpyAsync(Q[i], e->W[0], sizeof(double) * e->Np * e->ns * e->nreal,
                                hipMemcpyDeviceToDevice, e->s_comp) != hipSuccess)
                 return e->fail(CMDG_ERR_HIP, "lsrk: copy back failed");
+        // user callback EveryXSimulationSteps(1) of heldsuarez.jl:261-272
+        if (e->step_filter)
+            if (int r = e->filter_apply(e->step_filter, Q[i], e->ns)) return r;
+    }
+    return CMDG_OK;
+}
+
+// ---- Filters.apply_async!   Filters.jl:440-607 ----------------------------------------
+int EngineBase::filter_create(const cmdg_filter_desc *d, FilterObj **out)
+{
+    if (d->kind < CMDG_FILTER_SPECTRAL || d->kind > CMDG_FILTER_TMAR)
+        return fail(CMDG_ERR_INVALID, "filter: unknown kind");
+    if (d->target < CMDG_TARGET_INDICES || d->target > CMDG_TARGET_ATMOS_SPECIFIC_PERTURBATIONS)
+        return fail(CMDG_ERR_INVALID, "filter: unknown target");
+    if (d->direction < 0 || d->direction > 2) return fail(CMDG_ERR_INVALID, "filter: bad direction");
+    if (d->kind == CMDG_FILTER_TMAR && d->target != CMDG_TARGET_INDICES)
+        return fail(CMDG_ERR_INVALID, "TMAR filter takes FilterIndices targets");
+    if (d->target == CMDG_TARGET_INDICES) {
+        if (d->nindices < 1 || d->nindices > CMDG_MAX_FILTER_STATES)
+            return fail(CMDG_ERR_INVALID, "filter: 1..32 filtered states");
+        for (int i = 0; i < d->nindices; ++i)
+            if (d->indices[i] < 1) return fail(CMDG_ERR_INVALID, "filter: indices are 1-based");
+    } else if (d->aux_ref_rho < 0 || d->aux_ref_rho >= naux || d->aux_ref_rhoe < 0 ||
+               d->aux_ref_rhoe >= naux) {
+        return fail(CMDG_ERR_INVALID, "filter: reference-state columns outside state_auxiliary");
+    }
+    if (d->kind != CMDG_FILTER_TMAR && (!d->filter_h || !d->filter_v))
+        return fail(CMDG_ERR_INVALID, "filter: filter matrices are NULL");
+    FilterObj *f = new (std::nothrow) FilterObj();
+    if (!f) return fail(CMDG_ERR_INVALID, "filter: out of memory");
+    f->kind = d->kind;
+    f->target = d->target;
+    f->direction = d->direction;
+    f->nindices = d->nindices;
+    for (int i = 0; i < CMDG_MAX_FILTER_STATES; ++i) f->indices[i] = d->indices[i];
+    f->aux_ref_rho = d->aux_ref_rho;
+    f->aux_ref_rhoe = d->aux_ref_rhoe;
+    if (d->kind != CMDG_FILTER_TMAR) {
+        const size_t nb = sizeof(double) * NQ * NQ;
+        if (hipMalloc(&f->d_Fh, nb) != hipSuccess || hipMalloc(&f->d_Fv, nb) != hipSuccess ||
+            hipMemcpy(f->d_Fh, d->filter_h, nb, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(f->d_Fv, d->filter_v, nb, hipMemcpyHostToDevice) != hipSuccess) {
+            if (f->d_Fh) hipFree(f->d_Fh);
+            if (f->d_Fv) hipFree(f->d_Fv);
+            delete f;
+            return fail(CMDG_ERR_HIP, "filter: upload of the filter matrices failed");
         }
+    }
+    *out = f;
+    return CMDG_OK;
+}
+
+template <int NQ_>
+static void launch_filter(const FilterObj *f, const FilterArgs &a, int nfs, int64_t nreal,
+                          hipStream_t st)
+{
+    const dim3 grid((unsigned)nreal), block(FDims<NQ_>::NT);
+    const size_t lds = sizeof(double) * 2 * nfs * FDims<NQ_>::Np;
+    auto spectral = [&](auto K) { hipLaunchKernelGGL(K, grid, block, lds, st, a); };
+    if (f->kind == CMDG_FILTER_TMAR) {
+        hipLaunchKernelGGL((k_apply_tmar_filter<NQ_>), grid, dim3(64), 0, st, a);
+    } else if (f->kind == CMDG_FILTER_SPECTRAL) {
+        if (f->target == CMDG_TARGET_INDICES) spectral(k_apply_filter<NQ_, TGT_INDICES>);
+        else if (f->target == CMDG_TARGET_ATMOS_PERTURBATIONS) spectral(k_apply_filter<NQ_, TGT_ATMOS_PERT>);
+        else spectral(k_apply_filter<NQ_, TGT_ATMOS_SPECIFIC>);
+    } else {
+        if (f->target == CMDG_TARGET_INDICES) spectral(k_apply_mp_filter<NQ_, TGT_INDICES>);
+        else if (f->target == CMDG_TARGET_ATMOS_PERTURBATIONS) spectral(k_apply_mp_filter<NQ_, TGT_ATMOS_PERT>);
+        else spectral(k_apply_mp_filter<NQ_, TGT_ATMOS_SPECIFIC>);
+    }
+}
+
+int EngineBase::filter_apply(const FilterObj *f, double *Q, int nstate)
+{
+    if (!f || !Q) return fail(CMDG_ERR_INVALID, "filter: NULL argument");
+    if (NQ != 5) return fail(CMDG_ERR_UNSUPPORTED, "filter: polynomial order not compiled in");
+    if (nreal <= 0) return CMDG_OK;
+    FilterArgs a{};
+    a.Q = Q;
+    a.aux = aux;
+    a.vgeo = g.vgeo;
+    a.Fh = f->d_Fh;
+    a.Fv = f->d_Fv;
+    a.nstate = nstate;
+    a.naux = naux;
+    a.nvgeo = g.nvgeo;
+    a.aux_rho = f->aux_ref_rho;
+    a.aux_rhoe = f->aux_ref_rhoe;
+    a.nreal = nreal;
+    if (f->target == CMDG_TARGET_INDICES) {
+        for (int i = 0; i < f->nindices; ++i)
+            if (f->indices[i] > nstate) return fail(CMDG_ERR_INVALID, "filter: index beyond nstate");
+    } else if (nstate != ATMOS_NS) {
+        return fail(CMDG_ERR_INVALID, "filter: atmos targets need the 5-variable dry state");
+    }
+    const bool every = f->direction == DIR_EVERY;
+    const bool h = every || f->direction == DIR_HORIZONTAL, v = every || f->direction == DIR_VERTICAL;
+    // FilterIndices states are independent: at most CHUNK of them share the LDS of a launch
+    constexpr int CHUNK = 16;
+    const int ntot = f->target == CMDG_TARGET_INDICES ? f->nindices : ATMOS_NS;
+    for (int c0 = 0; c0 < ntot; c0 += CHUNK) {
+        const int nfs = std::min(CHUNK, ntot - c0);
+        a.nfs = nfs;
+        for (int i = 0; i < nfs; ++i) a.idx[i] = f->indices[c0 + i];
+        prof_begin(CMDG_K_FILTER, s_comp);
+        if (f->kind == CMDG_FILTER_MASS_PRESERVING) {
+            // one launch per direction, each with its own mass correction (Filters.jl:566-605)
+            if (h) {
+                a.do_h = 1, a.do_v = 0;
+                launch_filter<5>(f, a, nfs, nreal, s_comp);
+            }
+            if (v) {
+                a.do_h = 0, a.do_v = 1;
+                launch_filter<5>(f, a, nfs, nreal, s_comp);
+            }
+        } else {
+            a.do_h = h, a.do_v = v;
+            launch_filter<5>(f, a, nfs, nreal, s_comp);
+        }
+        prof_end(s_comp);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CMDG_ERR_HIP, std::string("filter launch: ") + hipGetErrorString(e));
     return CMDG_OK;
 }
 
@@ -743,6 +881,52 @@ int cmdg_distance2_local(cmdg_handle h, const double *A, const double *B, int32_
 {
     if (!h || !A || !B || !out_host) return CMDG_ERR_INVALID;
     return set_err(h, h->eng->wsum2(A, B, nstate, 1, out_host));
+}
+
+int cmdg_filter_create(cmdg_handle h, const cmdg_filter_desc *d, cmdg_filter *out)
+{
+    if (!h || !d || !out) return CMDG_ERR_INVALID;
+    FilterObj *f = nullptr;
+    int r = h->eng->filter_create(d, &f);
+    *out = reinterpret_cast<cmdg_filter>(f);
+    return set_err(h, r);
+}
+
+int cmdg_filter_destroy(cmdg_handle h, cmdg_filter f)
+{
+    if (!h || !f) return CMDG_ERR_INVALID;
+    EngineBase *e = h->eng;
+    FilterObj *o = reinterpret_cast<FilterObj *>(f);
+    e->synchronize();
+    if (e->gradient_filter == o) e->gradient_filter = nullptr;
+    if (e->tendency_filter == o) e->tendency_filter = nullptr;
+    if (e->step_filter == o) e->step_filter = nullptr;
+    if (o->d_Fh) hipFree(o->d_Fh);
+    if (o->d_Fv) hipFree(o->d_Fv);
+    delete o;
+    return CMDG_OK;
+}
+
+int cmdg_filter_apply(cmdg_handle h, cmdg_filter f, double *Q, int32_t nstate)
+{
+    if (!h || !f || !Q || nstate < 1) return CMDG_ERR_INVALID;
+    return set_err(h, h->eng->filter_apply(reinterpret_cast<FilterObj *>(f), Q, nstate));
+}
+
+int cmdg_set_filters(cmdg_handle h, cmdg_filter gradient_filter, cmdg_filter tendency_filter,
+                     cmdg_filter step_filter)
+{
+    if (!h) return CMDG_ERR_INVALID;
+    EngineBase *e = h->eng;
+    auto *gfl = reinterpret_cast<FilterObj *>(gradient_filter);
+    auto *tfl = reinterpret_cast<FilterObj *>(tendency_filter);
+    for (FilterObj *o : {gfl, tfl})
+        if (o && o->target != CMDG_TARGET_INDICES)
+            return set_err(h, e->fail(CMDG_ERR_INVALID, "gradient/tendency filters take FilterIndices targets"));
+    e->gradient_filter = gfl;
+    e->tendency_filter = tfl;
+    e->step_filter = reinterpret_cast<FilterObj *>(step_filter);
+    return CMDG_OK;
 }
 
 int cmdg_profile_enable(cmdg_handle h, int32_t on)

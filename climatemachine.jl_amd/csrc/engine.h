@@ -31,8 +31,18 @@ struct RhsCtx {
     double *Qin = nullptr;   // state read by this evaluation (ghosts refreshed in place)
     double *Qout = nullptr;  // LSRK: updated state
     double t = 0, alpha = 1, beta = 0;
-    bool lsrk = false;
+    bool lsrk = false;         // fused update inside k_tendency
+    bool update_after = false; // separate update!() after the (filtered) tendency
     double rkb_dt = 0, rka_next = 0;
+};
+
+// one `Filters.apply!` call site: filter + target + direction (include/cmdg.h)
+struct FilterObj {
+    int kind = 0, target = 0, direction = 0;
+    int nindices = 0;
+    int indices[CMDG_MAX_FILTER_STATES] = {0};
+    int aux_ref_rho = 0, aux_ref_rhoe = 0;
+    double *d_Fh = nullptr, *d_Fv = nullptr;
 };
 
 struct ProfRec {
@@ -69,6 +79,8 @@ struct EngineBase {
     int rank = 0, nranks = 1;
     std::vector<EngineBase *> group;    // local transport: engine of every rank
     void *nccl_comm = nullptr;
+    const FilterObj *gradient_filter = nullptr, *tendency_filter = nullptr,
+                    *step_filter = nullptr;
     bool profiling = false;
     std::vector<ProfRec> prof;
     double prof_ms[CMDG_K_COUNT] = {0};
@@ -105,6 +117,8 @@ struct EngineBase {
     int ensure_work();
     int synchronize();
     int wsum2(const double *A, const double *B, int nvar, int weighted, double *out);
+    int filter_create(const cmdg_filter_desc *d, FilterObj **out);
+    int filter_apply(const FilterObj *f, double *Q, int nstate);
 
     // profiling brackets
     void prof_begin(int kernel, hipStream_t st);

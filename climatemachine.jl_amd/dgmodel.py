@@ -164,6 +164,16 @@ class DGModel:
             self.handle)
 
     # -- transport --------------------------------------------------------------------
+    def set_filters(self, gradient_filter=None, tendency_filter=None, step_filter=None):
+        """``DGModel(...; gradient_filter, tendency_filter)`` (DGModel.jl:44-45, applied at
+        :185-193 and :417-425) and the every-step user filter callback of
+        ``experiments/AtmosGCM/heldsuarez.jl:261-272``.  Arguments are
+        ``mesh.filters.DeviceFilter`` objects (or None) bound to this model."""
+        fs = (gradient_filter, tendency_filter, step_filter)
+        self._filters = fs          # keep them alive
+        hs = [f.handle if f is not None else None for f in fs]
+        _lib.check(self.L.cmdg_set_filters(self.handle, *hs), self.handle)
+
     def comm_init_rccl(self, unique_id, rank, nranks):
         """``unique_id``: the 128 bytes of ``rccl_unique_id()`` made on rank 0."""
         _lib.check(self.L.cmdg_comm_init_rccl(self.handle, bytes(unique_id), int(rank),

@@ -153,10 +153,53 @@ int cmdg_norm2_local(cmdg_handle h, const double *A, int32_t nstate, int32_t wei
 int cmdg_distance2_local(cmdg_handle h, const double *A, const double *B, int32_t nstate,
                          double *out_host);
 
+/* ---- element filters (src/Numerics/Mesh/Filters.jl) ------------------------------ */
+typedef struct cmdg_filter_s *cmdg_filter;
+/* AbstractFilter: spectral = Exponential / BoydVandeven / Cutoff (Filters.jl:172-307,
+ * kernel_apply_filter! :651-794); MassPreservingCutoffFilter (:316-347, kernel :893-1071);
+ * TMARFilter (:369, kernel :796-884) */
+enum { CMDG_FILTER_SPECTRAL = 0, CMDG_FILTER_MASS_PRESERVING = 1, CMDG_FILTER_TMAR = 2 };
+/* AbstractFilterTarget: FilterIndices (Filters.jl:72-100), AtmosFilterPerturbations and
+ * AtmosSpecificFilterPerturbations (src/Atmos/Model/filters.jl:4-118, dry model: the
+ * state is rho, rho u[3], rho e and the reference state is read from state_auxiliary) */
+enum {
+    CMDG_TARGET_INDICES = 0, CMDG_TARGET_ATMOS_PERTURBATIONS = 1,
+    CMDG_TARGET_ATMOS_SPECIFIC_PERTURBATIONS = 2
+};
+#define CMDG_MAX_FILTER_STATES 32
+typedef struct cmdg_filter_desc {
+    int32_t kind;        /* CMDG_FILTER_* */
+    int32_t target;      /* CMDG_TARGET_* */
+    int32_t direction;   /* CMDG_*_DIRECTION keyword of Filters.apply! (spectral kinds) */
+    int32_t nindices;    /* FilterIndices: number of filtered states */
+    int32_t indices[CMDG_MAX_FILTER_STATES]; /* 1-based state indices */
+    int32_t aux_ref_rho, aux_ref_rhoe; /* atmos targets: 0-based state_auxiliary columns of
+                                          ref_state.rho and ref_state.rho e */
+    const double *filter_h; /* HOST (Nq, Nq) column-major filter.filter_matrices[1] */
+    const double *filter_v; /* HOST (Nq, Nq) column-major filter.filter_matrices[end] */
+} cmdg_filter_desc;
+/* filter object bound to a handle: the filter struct + target + direction of one
+ * `Filters.apply!(Q, target, grid, filter; direction, state_auxiliary)` call site */
+int cmdg_filter_create(cmdg_handle h, const cmdg_filter_desc *d, cmdg_filter *out);
+int cmdg_filter_destroy(cmdg_handle h, cmdg_filter f);
+/* Filters.apply_async! (Filters.jl:440-607): enqueue on the handle's compute stream, real
+ * elements only, in place.  Q is a device array (Np, nstate, nelem); atmos targets read the
+ * handle's state_auxiliary.  Follow with cmdg_synchronize for Filters.apply! (:408-421). */
+int cmdg_filter_apply(cmdg_handle h, cmdg_filter f, double *Q, int32_t nstate);
+/* filters the DG operator and the time stepper apply themselves:
+ *   gradient_filter  on state_gradient_flux after the gradient pass   (DGModel.jl:185-193)
+ *   tendency_filter  on the tendency at the end of the evaluation      (DGModel.jl:417-425)
+ *   step_filter      on Q after every completed LSRK step -- the EveryXSimulationSteps(1)
+ *                    callback of experiments/AtmosGCM/heldsuarez.jl:261-272
+ * NULL clears a slot.  The filters must outlive their use. */
+int cmdg_set_filters(cmdg_handle h, cmdg_filter gradient_filter, cmdg_filter tendency_filter,
+                     cmdg_filter step_filter);
+
 /* ---- measurement --------------------------------------------------------------- */
 enum {
     CMDG_K_GRADIENTS = 0, CMDG_K_DIVGRAD = 1, CMDG_K_GRADLAP = 2, CMDG_K_TENDENCY = 3,
-    CMDG_K_PACK = 4, CMDG_K_UNPACK = 5, CMDG_K_UPDATE_AUX = 6, CMDG_K_COUNT = 7
+    CMDG_K_PACK = 4, CMDG_K_UNPACK = 5, CMDG_K_UPDATE_AUX = 6, CMDG_K_FILTER = 7,
+    CMDG_K_COUNT = 8
 };
 /* bracket every launch with HIP events on the launch stream (off by default) */
 int cmdg_profile_enable(cmdg_handle h, int32_t on);

@@ -126,6 +126,27 @@ void orc_fillsendbuf(double *sendbuf, const double *buf, const int64_t *vmapsend
                      int Np, int nvar);
 void orc_transferrecvbuf(double *buf, const double *recvbuf, const int64_t *vmaprecv,
                          int64_t nvmap, int Np, int nvar);
+/* ---- element filters (filter_oracle.c) ------------------------------------------- */
+/* filter target: kind 0 FilterIndices (idx 1-based), 1 AtmosFilterPerturbations,
+ * 2 AtmosSpecificFilterPerturbations (aux_ref_*: 0-based aux columns of ref_state.rho, .rho e) */
+typedef struct orc_filter_target {
+    int kind, nfs;
+    int idx[ORC_MAXS];
+    int aux_ref_rho, aux_ref_rhoe;
+} orc_filter_target;
+/* Filters.jl:651-794; `direction` is the kernel's direction argument */
+void orc_apply_filter(int dim, const int *Nq, int direction, double *Q, int nstate,
+                      const double *aux, int naux, const orc_filter_target *tg, const double *F,
+                      int64_t nrealelem);
+/* Filters.jl:796-884 */
+void orc_apply_tmar_filter(int dim, const int *Nq, double *Q, int nstate,
+                           const orc_filter_target *tg, const double *vgeo, int nvgeo, int Mcol,
+                           int64_t nrealelem);
+/* Filters.jl:893-1071 */
+void orc_apply_mp_filter(int dim, const int *Nq, int direction, double *Q, int nstate,
+                         const double *aux, int naux, const orc_filter_target *tg,
+                         const double *F, const double *vgeo, int nvgeo, int Mcol,
+                         int64_t nrealelem);
 void orc_set_num_threads(int n);
 int orc_get_max_threads(void);
 #ifdef __cplusplus

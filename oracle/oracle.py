@@ -160,6 +160,9 @@ class OracleDGModel:
         self.Qhypervisc_div = np.zeros((ne, self.ph.nhyp, Np))
         self.exchange = exchange or NoExchange()
         self.L = lib()
+        # (filter, target) pairs: DGModel(...; gradient_filter, tendency_filter) DGModel.jl:44-45
+        self.gradient_filter = None
+        self.tendency_filter = None
 
     # -- launchers (SpaceDiscretization.jl) ----------------------------------
     def _dirs(self, d):
@@ -280,6 +283,9 @@ class OracleDGModel:
                 ex.end(Q, ph.ns, tok_Q)
                 self.update_auxiliary_state(Q, t, "ghost")
             self.launch_interface_gradients(Q, t, "exterior")
+            if self.gradient_filter is not None:      # DGModel.jl:185-193
+                apply_filter(self.state_gradient_flux, self.gradient_filter[1], self.grid,
+                             self.gradient_filter[0])
             if communicate:
                 if ph.ngf > 0:
                     tok_gf = ex.begin(self.state_gradient_flux, ph.ngf)
@@ -312,6 +318,8 @@ class OracleDGModel:
                 ex.end(Q, ph.ns, tok_Q)
                 self.update_auxiliary_state(Q, t, "ghost")
         self.launch_interface_tendency(tendency, Q, t, alpha, "exterior")
+        if self.tendency_filter is not None:          # DGModel.jl:417-425
+            apply_filter(tendency, self.tendency_filter[1], self.grid, self.tendency_filter[0])
 
 
 # ---- LSRK54 Carpenter-Kennedy (LowStorageRungeKuttaMethod.jl:293-327) -------------
@@ -328,15 +336,20 @@ RKC = (0.0, _f(1432997174477, 9575080441755), _f(2526269341429, 6820363962896),
        _f(2006345519317, 3224310063776), _f(2802321613138, 2924317926251))
 
 
-def lsrk54_step(dg, Q, dQ, t, dt):
+def lsrk54_step(dg, Q, dQ, t, dt, step_filter=None):
     """``dostep!`` (LowStorageRungeKuttaMethod.jl:102-144): ``rhs!(dQ, Q, p, t + c dt,
-    increment = true)`` then ``update!`` on the real elements."""
+    increment = true)`` then ``update!`` on the real elements.  ``step_filter`` =
+    ``(filter, target, direction)`` applied to Q after the step (the every-step callback
+    of experiments/AtmosGCM/heldsuarez.jl:261-272)."""
     nreal = dg.grid.nreal
     n = nreal * Q.shape[1] * Q.shape[2]
     for s in range(5):
         dg(dQ, Q, t + RKC[s] * dt, 1.0, 1.0)
         lib().orc_lsrk_update(_p(dQ), _p(Q), C.c_double(RKA[(s + 1) % 5]),
                               C.c_double(RKB[s]), C.c_double(dt), C.c_int64(n))
+    if step_filter is not None:
+        f, tg, d = step_filter
+        apply_filter(Q, tg, dg.grid, f, direction=d, state_auxiliary=dg.state_auxiliary)
 
 
 def solve(dg, Q, dt, timeend, t0=0.0):
@@ -363,3 +376,57 @@ def weighted_norm2_local(grid, A, B=None):
     M = grid.vgeo[:nreal, 9, :][:, None, :]
     d = A[:nreal] if B is None else A[:nreal] - B[:nreal]
     return float(np.sum(M * d * d))
+
+
+# ---- element filters (filter_oracle.c) --------------------------------------------------
+class _FilterTarget(C.Structure):
+    _fields_ = [("kind", C.c_int), ("nfs", C.c_int), ("idx", C.c_int * MAXS),
+                ("aux_ref_rho", C.c_int), ("aux_ref_rhoe", C.c_int)]
+
+
+def _c_target(target):
+    """``target``: an object with ``target_id``, ``indices`` (1-based) and ``aux_offsets()``
+    (the host classes of ``mesh/filters.py``)."""
+    t = _FilterTarget()
+    t.kind, t.nfs = target.target_id, len(target.indices)
+    for i, v in enumerate(target.indices):
+        t.idx[i] = v
+    t.aux_ref_rho, t.aux_ref_rhoe = target.aux_offsets()
+    return t
+
+
+def apply_filter(Q, target, grid, filt, direction=EVERY, state_auxiliary=None):
+    """``Filters.apply!(Q, target, grid, filter; direction, state_auxiliary)`` restated:
+    the launch sequence of ``apply_async!`` (Filters.jl:440-505 spectral, :507-540 TMAR,
+    :542-607 mass preserving) over the C kernels.  ``Q``: numpy ``(nelem, nstate, Np)``,
+    filtered in place on the real elements; works for 2-D and 3-D grids."""
+    L = lib()
+    assert Q.flags.c_contiguous and Q.dtype == np.float64
+    dim, nstate = grid.dim, Q.shape[1]
+    Nq = (C.c_int * 3)(*(list(grid.Nq) + [1] * (3 - dim)))
+    tg = _c_target(target)
+    nreal = C.c_int64(grid.nreal)
+    if state_auxiliary is None:
+        aux, naux = None, 0
+    else:
+        aux = np.ascontiguousarray(state_auxiliary, dtype=np.float64)
+        naux = aux.shape[1]
+    auxp = _p(aux) if aux is not None else None
+    vgeo = np.ascontiguousarray(grid.vgeo, dtype=np.float64)
+    MCOL = 9     # _M, Grids.jl:129-146
+    if filt.kind == 2:
+        L.orc_apply_tmar_filter(dim, Nq, _p(Q), nstate, C.byref(tg), _p(vgeo), vgeo.shape[1],
+                                MCOL, nreal)
+        return
+    calls = []
+    if direction in (EVERY, HORIZONTAL):
+        calls.append((HORIZONTAL, filt.filter_matrices[0]))
+    if direction in (EVERY, VERTICAL):
+        calls.append((VERTICAL, filt.filter_matrices[-1]))
+    for d, F in calls:
+        Fc = np.ascontiguousarray(np.asarray(F, dtype=np.float64).T)    # column-major
+        if filt.kind == 0:
+            L.orc_apply_filter(dim, Nq, d, _p(Q), nstate, auxp, naux, C.byref(tg), _p(Fc), nreal)
+        else:
+            L.orc_apply_mp_filter(dim, Nq, d, _p(Q), nstate, auxp, naux, C.byref(tg), _p(Fc),
+                                  _p(vgeo), vgeo.shape[1], MCOL, nreal)

@@ -38,11 +38,11 @@ def test_queries_work_without_a_gpu():
     assert L.cmdg_status_string(-5) == b"unsupported physics / polynomial order"
 
 
-def test_desc_struct_matches_header_field_order():
+def _header_fields(struct):
     txt = open(os.path.join(ROOT, "include", "cmdg.h")).read()
-    body = txt[txt.index("typedef struct cmdg_desc {"):txt.index("} cmdg_desc;")]
+    body = txt[txt.index("typedef struct %s {" % struct):txt.index("} %s;" % struct)]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    body = body.replace("typedef struct cmdg_desc {", "")
+    body = body.replace("typedef struct %s {" % struct, "")
     fields = []
     for stmt in body.split(";"):
         stmt = " ".join(stmt.split())
@@ -54,4 +54,17 @@ def test_desc_struct_matches_header_field_order():
             nm = re.sub(r"\[.*\]", "", nm).replace("*", "").strip()
             if nm:
                 fields.append(nm)
+    return fields
+
+
+def test_desc_struct_matches_header_field_order():
+    fields = _header_fields("cmdg_desc")
     assert fields == [f[0] for f in cm._lib.CmdgDesc._fields_], fields
+
+
+def test_filter_desc_struct_matches_header_field_order():
+    fields = _header_fields("cmdg_filter_desc")
+    F = cm.mesh.filters
+    assert fields == [f[0] for f in F.CmdgFilterDesc._fields_], fields
+    txt = open(os.path.join(ROOT, "include", "cmdg.h")).read()
+    assert "#define CMDG_MAX_FILTER_STATES %d" % F.MAX_FILTER_STATES in txt
