@@ -59,6 +59,8 @@ SYMBOLS = [
     ("cmdg_group_lsrk_run", C.c_int, [_vp, _i32, _vp, _vp, _d, _d, _i64, _i32, _vp, _vp, _vp]),
     ("cmdg_norm2_local", C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     ("cmdg_distance2_local", C.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    ("cmdg_courant", C.c_int, [_vp, _i32, _vp, _d, _d, _i32, _vp]),
+    ("cmdg_min_node_distance", C.c_int, [_vp, _i32, _vp]),
     ("cmdg_filter_create", C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     ("cmdg_filter_destroy", C.c_int, [_vp, _vp]),
     ("cmdg_filter_apply", C.c_int, [_vp, _vp, _vp, _i32]),

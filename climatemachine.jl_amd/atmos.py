@@ -110,6 +110,25 @@ class IsentropicVortexSetup:
         return rho, [rho * u[0], rho * u[1], rho * u[2]], rhoe
 
 
+class CourantTestSetup:
+    """``initialcondition!`` of test/Numerics/DGMethods/courant.jl:31-60: isothermal air at
+    ``T_inf``, ``p_inf`` moving with ``u = 150 x (1, 1, 0)``; the potential energy passed to
+    ``total_energy`` is zero there."""
+
+    def __init__(self, ps, p_inf=1e5, T_inf=300.0, translation_speed=150.0):
+        self.ps, self.p_inf, self.T_inf, self.speed = ps, p_inf, T_inf, translation_speed
+
+    def __call__(self, law, aux, coord, t):
+        ps = self.ps
+        u = [self.speed * coord[0], self.speed * coord[0], 0.0 * coord[0]]
+        T = self.T_inf
+        p = self.p_inf * (T / self.T_inf) ** (1.0 / ps.kappa_d)
+        rho = p / (ps.R_d * T) + 0.0 * coord[0]
+        e_kin = (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) / 2
+        rhoe = rho * (e_kin + 0.0 + ps.cv_d * (T - ps.T_0))
+        return rho, [rho * u[0], rho * u[1], rho * u[2]], rhoe
+
+
 class HeldSuarezSetup:
     """``init_heldsuarez!`` (experiments/AtmosGCM/heldsuarez.jl:47-104)."""
 

@@ -82,6 +82,7 @@ EngineBase::~EngineBase()
     if (d_D) hipFree(d_D);
     if (derived) hipFree(derived);
     if (d_partial) hipFree(d_partial);
+    if (d_elemred) hipFree(d_elemred);
     if (ev_comp) hipEventDestroy(ev_comp);
     if (nccl_comm && rccl::CommDestroy) rccl::CommDestroy(nccl_comm);
     if (s_comp) hipStreamDestroy(s_comp);
@@ -461,6 +462,25 @@ int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, doubl
         if (e->step_filter)
             if (int r = e->filter_apply(e->step_filter, Q[i], e->ns)) return r;
     }
+    return CMDG_OK;
+}
+
+// ---- courant / min_node_distance: rank-local extremum, the caller Allreduces ------------
+int EngineBase::courant(int mode, int kind, const double *Q, double dt, double t, int dir,
+                        double *out)
+{
+    if (dir < 0 || dir > 2 || kind < 0 || kind > 2) return fail(CMDG_ERR_INVALID, "courant: bad argument");
+    if (g.nvgeo < 15) return fail(CMDG_ERR_INVALID, "courant: vgeo lacks the coordinate columns");
+    if (nreal == 0) {  // typemin / typemax (SpaceDiscretization.jl:359-361, Grids.jl:481-483)
+        *out = mode == 0 ? INFINITY : -INFINITY;
+        return CMDG_OK;
+    }
+    if (!d_elemred) HIPCHK(hipMalloc(&d_elemred, sizeof(double) * (nreal + 1)));
+    if (int r = launch_courant(mode, kind, Q, dt, t, dir, d_elemred)) return r;
+    hipLaunchKernelGGL(k_extremum, dim3(1), dim3(1024), 0, s_comp, d_elemred, nreal, mode == 0,
+                       d_elemred + nreal);
+    HIPCHK(hipMemcpyAsync(out, d_elemred + nreal, sizeof(double), hipMemcpyDeviceToHost, s_comp));
+    HIPCHK(hipStreamSynchronize(s_comp));
     return CMDG_OK;
 }
 
@@ -881,6 +901,19 @@ int cmdg_distance2_local(cmdg_handle h, const double *A, const double *B, int32_
 {
     if (!h || !A || !B || !out_host) return CMDG_ERR_INVALID;
     return set_err(h, h->eng->wsum2(A, B, nstate, 1, out_host));
+}
+
+int cmdg_courant(cmdg_handle h, int32_t kind, const double *Q, double dt, double simtime,
+                 int32_t direction, double *out_host)
+{
+    if (!h || !Q || !out_host) return CMDG_ERR_INVALID;
+    return set_err(h, h->eng->courant(1, kind, Q, dt, simtime, direction, out_host));
+}
+
+int cmdg_min_node_distance(cmdg_handle h, int32_t direction, double *out_host)
+{
+    if (!h || !out_host) return CMDG_ERR_INVALID;
+    return set_err(h, h->eng->courant(0, 0, nullptr, 0.0, 0.0, direction, out_host));
 }
 
 int cmdg_filter_create(cmdg_handle h, const cmdg_filter_desc *d, cmdg_filter *out)

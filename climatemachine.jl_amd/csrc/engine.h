@@ -105,6 +105,9 @@ struct EngineBase {
     virtual bool has_update_aux() const = 0;
     virtual bool fused_update_aux() const = 0;
     virtual int init_derived() = 0;
+    // mode 0: per-element minimum node distance, mode 1: per-element maximum Courant number
+    virtual int launch_courant(int mode, int kind, const double *Q, double dt, double t, int dir,
+                               double *out_elem) = 0;
 
     // orchestration
     static constexpr int NSEG = 5;
@@ -117,6 +120,8 @@ struct EngineBase {
     int ensure_work();
     int synchronize();
     int wsum2(const double *A, const double *B, int nvar, int weighted, double *out);
+    int courant(int mode, int kind, const double *Q, double dt, double t, int dir, double *out);
+    double *d_elemred = nullptr;  // (nreal) per-element extrema
     int filter_create(const cmdg_filter_desc *d, FilterObj **out);
     int filter_apply(const FilterObj *f, double *Q, int nstate);
 
@@ -218,6 +223,20 @@ struct EngineT : EngineBase {
                                0, s_comp, prm, c.Qin, aux, d_activedofs, c.t, e0, e1);
             prof_end(s_comp);
         }
+    }
+    int launch_courant(int mode, int kind, const double *Q, double dt, double t, int dir,
+                       double *out_elem) override
+    {
+        constexpr int NT = KDims<NQ_>::Np <= 128 ? 128 : 256;
+        if (mode == 1 && !P::HAS_COURANT)
+            return fail(CMDG_ERR_UNSUPPORTED, "this balance law defines no local Courant number");
+        if (mode == 0)
+            hipLaunchKernelGGL((k_courant<P, NQ_, 0>), dim3((unsigned)nreal), dim3(NT), 0, s_comp, prm,
+                               g.vgeo, g.nvgeo, Q, aux, gf, kind, dt, t, dir, out_elem);
+        else
+            hipLaunchKernelGGL((k_courant<P, NQ_, 1>), dim3((unsigned)nreal), dim3(NT), 0, s_comp, prm,
+                               g.vgeo, g.nvgeo, Q, aux, gf, kind, dt, t, dir, out_elem);
+        return CMDG_OK;
     }
     bool has_update_aux() const override { return P::HAS_UPDATE_AUX; }
     bool fused_update_aux() const override { return P::HAS_UPDATE_AUX && P::FUSE_UPDATE_AUX; }

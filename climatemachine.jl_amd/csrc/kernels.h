@@ -938,4 +938,81 @@ static __global__ void k_wsum2(const double *__restrict__ A, const double *__res
     if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
 
+// ---- courant(local_courant, dg, m, Q, dt, t, direction)  SpaceDiscretization.jl:307-365 ----
+// One block per real element: node coordinates staged in LDS, the minimum neighbour distance
+// (kernel_min_neighbor_distance!, Grids.jl:1228-1333) and the law's local Courant number
+// (kernel_local_courant!, DGModel_kernels.jl:3028-3096) evaluated per node, then a block-wide
+// extremum.  MODE 0: out[e] = min distance of the element, MODE 1: out[e] = max Courant.
+template <class P, int NQ, int MODE>
+__global__ __launch_bounds__(KDims<NQ>::Np <= 128 ? 128 : 256) void k_courant(
+    typename P::Params prm, const double *__restrict__ vgeo, int nvgeo,
+    const double *__restrict__ Q, const double *__restrict__ aux, const double *__restrict__ gf,
+    int kind, double dt, double t, int direction, double *__restrict__ out)
+{
+    constexpr int Np = KDims<NQ>::Np, NT = Np <= 128 ? 128 : 256;
+    __shared__ double sx[3][Np], sred[NT];
+    const int tid = threadIdx.x;
+    const int64_t e = blockIdx.x;
+    constexpr int X1 = 12;  // _x1 (Grids.jl:76-92), 0-based column
+    for (int n = tid; n < Np; n += NT)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) sx[d][n] = vgeo[n + (int64_t)Np * (X1 + d + (int64_t)nvgeo * e)];
+    __syncthreads();
+    double val = MODE == 0 ? INFINITY : -INFINITY;
+    for (int n = tid; n < Np; n += NT) {
+        const int i = n % NQ, j = (n / NQ) % NQ, k = n / (NQ * NQ);
+        double md = INFINITY;
+        auto dist = [&](int m) {
+            const double d0 = sx[0][n] - sx[0][m], d1 = sx[1][n] - sx[1][m], d2 = sx[2][n] - sx[2][m];
+            return sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        };
+        if (direction != DIR_VERTICAL) {
+            if (i > 0) md = fmin(md, dist(n - 1));
+            if (i < NQ - 1) md = fmin(md, dist(n + 1));
+            if (j > 0) md = fmin(md, dist(n - NQ));
+            if (j < NQ - 1) md = fmin(md, dist(n + NQ));
+        }
+        if (direction != DIR_HORIZONTAL) {
+            if (k > 0) md = fmin(md, dist(n - NQ * NQ));
+            if (k < NQ - 1) md = fmin(md, dist(n + NQ * NQ));
+        }
+        if constexpr (MODE == 0) {
+            val = fmin(val, md);
+        } else {
+            Vec<P::NS> lQ;
+            Vec<P::NAUX> lA;
+            Vec<P::NGF> lG;
+            load_state<P::NS, Np>(lQ, Q, n, e);
+            load_state<P::NAUX, Np>(lA, aux, n, e);
+            if constexpr (P::NGF > 0) load_state<P::NGF, Np>(lG, gf, n, e);
+            val = fmax(val, P::courant(prm, kind, lQ, lA, lG, md, dt, t, direction));
+        }
+    }
+    sred[tid] = val;
+    __syncthreads();
+    for (int h = NT / 2; h > 0; h >>= 1) {
+        if (tid < h) sred[tid] = MODE == 0 ? fmin(sred[tid], sred[tid + h]) : fmax(sred[tid], sred[tid + h]);
+        __syncthreads();
+    }
+    if (tid == 0) out[e] = sred[0];
+}
+
+// extremum of n values into out[0] (one block)
+static __global__ void k_extremum(const double *__restrict__ v, int64_t n, int is_min,
+                                  double *__restrict__ out)
+{
+    __shared__ double s[1024];
+    double a = is_min ? INFINITY : -INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) a = is_min ? fmin(a, v[i]) : fmax(a, v[i]);
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int h = blockDim.x / 2; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h)
+            s[threadIdx.x] = is_min ? fmin(s[threadIdx.x], s[threadIdx.x + h])
+                                    : fmax(s[threadIdx.x], s[threadIdx.x + h]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
+
 }  // namespace cmdg

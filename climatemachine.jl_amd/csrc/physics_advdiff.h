@@ -236,6 +236,13 @@ struct AdvDiff {
         }
     }
     __device__ static void update_aux(const Params &, const double *, double *, double) {}
+    // the test law defines no local_courant function
+    static constexpr bool HAS_COURANT = false;
+    __device__ static double courant(const Params &, int, const double *, const double *,
+                                     const double *, double, double, double, int)
+    {
+        return 0.0;
+    }
 };
 
 }  // namespace cmdg

@@ -100,6 +100,36 @@ struct DryAtmos {
         return sqrt(gamma * m.R_d * T);
     }
 
+    // ---- local Courant numbers: src/Atmos/Model/courant.jl:12-83 ------------------------
+    static constexpr bool HAS_COURANT = true;
+    __device__ static double courant(const Params &m, int kind, const double *Q, const double *aux,
+                                     const double *, double dx, double dt, double, int direction)
+    {
+        double k[3] = {0, 0, 0};
+        if constexpr (ORIENT) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) k[d] = aux[OPHI + 1 + d] / m.grav;
+        }
+        if (kind == 2) {  // diffusive_courant; nu of the constant-viscosity closures
+            const double nu = m.kinematic ? m.visc : m.visc / Q[0];
+            return dt * nu / (dx * dx);
+        }
+        const double dotk = Q[1] * k[0] + Q[2] * k[1] + Q[3] * k[2];
+        double normu;
+        if (direction == DIR_VERTICAL) {
+            normu = fabs(dotk) / Q[0];
+        } else {
+            double v[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                v[d] = direction == DIR_HORIZONTAL ? (Q[1 + d] - dotk * k[d]) / Q[0] : Q[1 + d] / Q[0];
+            normu = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        }
+        if (kind == 0) return dt * normu / dx;
+        const double ss = soundspeed(m, air_T(m, internal_energy(m, Q, aux)));
+        return dt * (normu + ss) / dx;
+    }
+
     // ---- fluxes ----------------------------------------------------------------------
     __device__ static void flux_first_order(const Params &m, double *F, const double *Q,
                                             const double *aux, double, int)

@@ -19,7 +19,10 @@ import torch
 from . import _lib
 from .balancelaws import EveryDirection, RusanovNumericalFlux
 
-__all__ = ["DGModel", "connect_local", "group_rhs", "group_lsrk_run", "rccl_unique_id"]
+__all__ = ["DGModel", "connect_local", "group_rhs", "group_lsrk_run", "rccl_unique_id",
+           "ADVECTIVE_COURANT", "NONDIFFUSIVE_COURANT", "DIFFUSIVE_COURANT"]
+
+ADVECTIVE_COURANT, NONDIFFUSIVE_COURANT, DIFFUSIVE_COURANT = 0, 1, 2
 
 
 def _dev(a, device, dtype=None):
@@ -164,6 +167,28 @@ class DGModel:
             self.handle)
 
     # -- transport --------------------------------------------------------------------
+    # -- Courant numbers (SpaceDiscretization.jl:307-365, DGMethods.jl:79-83) ----------------
+    def courant(self, local_courant, Q, dt, simtime=0.0, direction=EveryDirection):
+        """``courant(local_courant, dg, m, Q, dt, simtime, direction)``: rank-local maximum;
+        ``local_courant`` is ``ADVECTIVE_COURANT``, ``NONDIFFUSIVE_COURANT`` or
+        ``DIFFUSIVE_COURANT``.  Multi-rank callers reduce with ``max``."""
+        out = C.c_double()
+        self._torch_ready()
+        _lib.check(self.L.cmdg_courant(self.handle, int(local_courant), Q.data_ptr(), float(dt),
+                                       float(simtime), int(direction), C.byref(out)), self.handle)
+        return out.value
+
+    def min_node_distance(self, direction=EveryDirection):
+        """``min_node_distance(grid, direction)`` (Grids.jl:455-486), rank-local."""
+        out = C.c_double()
+        _lib.check(self.L.cmdg_min_node_distance(self.handle, int(direction), C.byref(out)),
+                   self.handle)
+        return out.value
+
+    def calculate_dt(self, Q, courant_number, t=0.0, direction=EveryDirection):
+        """``calculate_dt(dg, model, Q, Courant_number, t, direction)`` (DGMethods.jl:79-83)."""
+        return courant_number / self.courant(NONDIFFUSIVE_COURANT, Q, 1.0, t, direction)
+
     def set_filters(self, gradient_filter=None, tendency_filter=None, step_filter=None):
         """``DGModel(...; gradient_filter, tendency_filter)`` (DGModel.jl:44-45, applied at
         :185-193 and :417-425) and the every-step user filter callback of

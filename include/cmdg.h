@@ -153,6 +153,20 @@ int cmdg_norm2_local(cmdg_handle h, const double *A, int32_t nstate, int32_t wei
 int cmdg_distance2_local(cmdg_handle h, const double *A, const double *B, int32_t nstate,
                          double *out_host);
 
+/* ---- Courant numbers and time-step selection ------------------------------------------ */
+/* local_courant functions of src/Atmos/Model/courant.jl:29-83 */
+enum { CMDG_ADVECTIVE_COURANT = 0, CMDG_NONDIFFUSIVE_COURANT = 1, CMDG_DIFFUSIVE_COURANT = 2 };
+/* courant(local_courant, dg, m, Q, dt, simtime, direction) (SpaceDiscretization.jl:307-365):
+ * maximum over this rank's real nodes of the law's local Courant number, with dx the
+ * minimum neighbour distance of the node in `direction`; -inf when the rank owns no element.
+ * The caller applies MPI.Allreduce(max) (:364).  calculate_dt (DGMethods.jl:79-83) is
+ * Courant_number / cmdg_courant(NONDIFFUSIVE, dt = 1).  Blocks until the value is on the host. */
+int cmdg_courant(cmdg_handle h, int32_t kind, const double *Q, double dt, double simtime,
+                 int32_t direction, double *out_host);
+/* min_node_distance(grid, direction) (Grids.jl:455-486): rank-local minimum, +inf for an empty
+ * rank; the caller applies MPI.Allreduce(min). */
+int cmdg_min_node_distance(cmdg_handle h, int32_t direction, double *out_host);
+
 /* ---- element filters (src/Numerics/Mesh/Filters.jl) ------------------------------ */
 typedef struct cmdg_filter_s *cmdg_filter;
 /* AbstractFilter: spectral = Exponential / BoydVandeven / Cutoff (Filters.jl:172-307,

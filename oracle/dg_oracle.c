@@ -807,3 +807,58 @@ void orc_transferrecvbuf(double *buf, const double *recvbuf, const int64_t *vmap
             buf[n + (int64_t)Np * (s + (int64_t)nvar * e)] = recvbuf[s + (int64_t)nvar * i];
     }
 }
+
+/* ---- Courant number (SpaceDiscretization.jl:307-365) --------------------------------- */
+static inline double dist3(const orc_grid *g, int a, int b, int64_t e)
+{
+    const double d0 = VG(g, a, 12, e) - VG(g, b, 12, e); /* _x1.._x3 = columns 13..15 */
+    const double d1 = VG(g, a, 13, e) - VG(g, b, 13, e);
+    const double d2 = VG(g, a, 14, e) - VG(g, b, 14, e);
+    return sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+}
+
+void orc_min_neighbor_distance(const orc_grid *g, int direction, double *out)
+{
+    const int Nq1 = g->Nq[0], Nq2 = g->Nq[1], Nqk = g->Nq[2], Np = g->Np;
+    const int m1 = direction != ORC_VERTICAL, m2 = direction != ORC_VERTICAL,
+              m3 = direction != ORC_HORIZONTAL;
+#pragma omp parallel for
+    for (int64_t e = 0; e < g->nreal; ++e)
+        for (int k = 0; k < Nqk; ++k)
+            for (int j = 0; j < Nq2; ++j)
+                for (int i = 0; i < Nq1; ++i) {
+                    const int ijk = i + Nq1 * (j + Nq2 * k);
+                    double md = INFINITY;
+                    if (m1)
+                        for (int ii = i - 1; ii <= i + 1; ii += 2)
+                            if (ii >= 0 && ii < Nq1)
+                                md = fmin(md, dist3(g, ijk, ii + Nq1 * (j + Nq2 * k), e));
+                    if (m2)
+                        for (int jj = j - 1; jj <= j + 1; jj += 2)
+                            if (jj >= 0 && jj < Nq2)
+                                md = fmin(md, dist3(g, ijk, i + Nq1 * (jj + Nq2 * k), e));
+                    if (m3)
+                        for (int kk = k - 1; kk <= k + 1; kk += 2)
+                            if (kk >= 0 && kk < Nqk)
+                                md = fmin(md, dist3(g, ijk, i + Nq1 * (j + Nq2 * kk), e));
+                    out[ijk + (int64_t)Np * e] = md;
+                }
+}
+
+void orc_local_courant(const orc_physics *ph, const orc_grid *g, int kind, double *pointwise,
+                       const double *Q, const double *aux, const double *gf, double dt,
+                       double simtime, int direction)
+{
+    const int Np = g->Np;
+#pragma omp parallel for
+    for (int64_t e = 0; e < g->nreal; ++e)
+        for (int n = 0; n < Np; ++n) {
+            double lQ[ORC_MAXS], lA[ORC_MAXS], lG[ORC_MAXS];
+            loadv(lQ, Q, n, ph->ns, e, Np);
+            loadv(lA, aux, n, ph->naux, e, Np);
+            loadv(lG, gf, n, ph->ngf, e, Np);
+            const double dx = pointwise[n + (int64_t)Np * e];
+            pointwise[n + (int64_t)Np * e] =
+                ph->courant(ph->p, kind, lQ, lA, lG, dx, dt, simtime, direction);
+        }
+}

@@ -63,6 +63,10 @@ typedef struct orc_physics {
                                         const double *auxM, const double *lapM, double t);
     /* nodal update_auxiliary_state! hook (NULL: the law's hook returns false) */
     void (*update_aux)(const void *p, const double *Q, double *aux, double t);
+    /* local_courant functions of the law (src/Atmos/Model/courant.jl): kind 0 advective,
+     * 1 nondiffusive, 2 diffusive; NULL when the law defines none */
+    double (*courant)(const void *p, int kind, const double *Q, const double *aux,
+                      const double *gf, double dx, double dt, double t, int direction);
 } orc_physics;
 
 typedef struct orc_grid {
@@ -126,6 +130,13 @@ void orc_fillsendbuf(double *sendbuf, const double *buf, const int64_t *vmapsend
                      int Np, int nvar);
 void orc_transferrecvbuf(double *buf, const double *recvbuf, const int64_t *vmaprecv,
                          int64_t nvmap, int Np, int nvar);
+/* Grids.jl:1228-1333 kernel_min_neighbor_distance!: out (Np, nreal) */
+void orc_min_neighbor_distance(const orc_grid *g, int direction, double *out);
+/* DGModel_kernels.jl:3028-3096 kernel_local_courant!: pointwise (Np, nreal) holds dx on
+ * entry and the local Courant number on return */
+void orc_local_courant(const orc_physics *ph, const orc_grid *g, int kind, double *pointwise,
+                       const double *Q, const double *aux, const double *gf, double dt,
+                       double simtime, int direction);
 /* ---- element filters (filter_oracle.c) ------------------------------------------- */
 /* filter target: kind 0 FilterIndices (idx 1-based), 1 AtmosFilterPerturbations,
  * 2 AtmosSpecificFilterPerturbations (aux_ref_*: 0-based aux columns of ref_state.rho, .rho e) */

@@ -45,7 +45,7 @@ class _Physics(C.Structure):
                     "flux_first_order", "flux_second_order", "source", "gradient_argument",
                     "gradient_flux", "post_gradient_laplacian", "wavespeed", "boundary_state",
                     "boundary_flux_second_order", "boundary_state_divergence",
-                    "boundary_state_higher_order", "update_aux")])
+                    "boundary_state_higher_order", "update_aux", "courant")])
 
 
 class _Grid(C.Structure):
@@ -376,6 +376,35 @@ def weighted_norm2_local(grid, A, B=None):
     M = grid.vgeo[:nreal, 9, :][:, None, :]
     d = A[:nreal] if B is None else A[:nreal] - B[:nreal]
     return float(np.sum(M * d * d))
+
+
+# ---- Courant numbers and time-step selection -------------------------------------------
+ADVECTIVE_COURANT, NONDIFFUSIVE_COURANT, DIFFUSIVE_COURANT = 0, 1, 2
+
+
+def min_neighbor_distance(og, direction=EVERY):
+    """Pointwise ``kernel_min_neighbor_distance!`` (Grids.jl:1228-1333): ``(nreal, Np)``."""
+    out = np.zeros((og.grid.nreal, og.grid.Np))
+    lib().orc_min_neighbor_distance(C.byref(og.c), int(direction), _p(out))
+    return out
+
+
+def courant(kind, dg, Q, dt, simtime=0.0, direction=EVERY):
+    """``courant(local_courant, dg, m, Q, dt, simtime, direction)``
+    (SpaceDiscretization.jl:307-365): rank-local maximum (the caller Allreduces)."""
+    if dg.grid.nreal == 0:
+        return -np.inf
+    pw = min_neighbor_distance(dg.og, direction)
+    gf = dg.state_gradient_flux
+    lib().orc_local_courant(dg.ph.c, C.byref(dg.og.c), int(kind), _p(pw), _p(Q),
+                            _p(dg.state_auxiliary), _p(gf), C.c_double(dt),
+                            C.c_double(simtime), int(direction))
+    return float(pw.max())
+
+
+def calculate_dt(dg, Q, courant_number, t=0.0, direction=EVERY):
+    """``calculate_dt(dg, model, Q, Courant_number, t, direction)`` (DGMethods.jl:79-83)."""
+    return courant_number / courant(NONDIFFUSIVE_COURANT, dg, Q, 1.0, t, direction)
 
 
 # ---- element filters (filter_oracle.c) --------------------------------------------------

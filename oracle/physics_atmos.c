@@ -295,6 +295,38 @@ static void at_update_aux(const void *p_, const double *Q, double *aux, double t
     moist_update((const atmos_t *)p_, Q, aux);
 }
 
+/* src/Atmos/Model/courant.jl:12-83 */
+static double at_courant(const void *p_, int kind, const double *Q, const double *aux,
+                         const double *gf, double dx, double dt, double t, int direction)
+{
+    const atmos_t *m = (const atmos_t *)p_;
+    (void)t;
+    double k[3] = {0, 0, 0};
+    if (m->orient)
+        for (int d = 0; d < 3; ++d) k[d] = aux[m->oPhi + 1 + d] / m->grav;
+    if (kind == 2) { /* diffusive_courant: nu is a scalar for the constant-viscosity closures */
+        double nu, Dt, tau[6];
+        turbulence_tensors(m, Q, gf, &nu, &Dt, tau);
+        return dt * nu / (dx * dx);
+    }
+    double normu;
+    const double dotk = Q[1] * k[0] + Q[2] * k[1] + Q[3] * k[2];
+    if (direction == ORC_VERTICAL) {
+        normu = fabs(dotk) / Q[0];
+    } else if (direction == ORC_HORIZONTAL) {
+        double v[3];
+        for (int d = 0; d < 3; ++d) v[d] = (Q[1 + d] - dotk * k[d]) / Q[0];
+        normu = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    } else {
+        double v[3];
+        for (int d = 0; d < 3; ++d) v[d] = Q[1 + d] / Q[0];
+        normu = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    }
+    if (kind == 0) return dt * normu / dx;
+    const double ss = soundspeed(m, air_T(m, internal_energy(m, Q, aux)));
+    return dt * (normu + ss) / dx;
+}
+
 orc_physics *orc_atmos_new(const int *ip, const double *dp, int nf_first)
 {
     orc_physics *ph = (orc_physics *)calloc(1, sizeof(orc_physics));
@@ -332,5 +364,6 @@ orc_physics *orc_atmos_new(const int *ip, const double *dp, int nf_first)
     ph->boundary_state_divergence = at_bdiv;
     ph->boundary_state_higher_order = at_bhigher;
     ph->update_aux = at_update_aux;
+    ph->courant = at_courant;
     return ph;
 }

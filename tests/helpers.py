@@ -85,3 +85,19 @@ def held_suarez_setup(n_horz=3, n_vert=2, N=4, rank=0, size=1):
                           boundary_conditions=(A.BC_ATMOS_DEFAULT, A.BC_ATMOS_DEFAULT),
                           param_set=ps)
     return law, grid, 0, 1
+
+
+def courant_test_setup(Neh=10, Nev=4, N=4, rank=0, size=1):
+    """test/Numerics/DGMethods/courant.jl:63-135 (dim = 3): stacked brick [0,1]^2 x [1,2],
+    FlatOrientation, NoReferenceState, ConstantDynamicViscosity(2), Gravity source."""
+    A = cm.atmos
+    ps = A.PlanetParameters()
+    rng = [np.linspace(0.0, 1.0, Neh + 1), np.linspace(0.0, 1.0, Neh + 1),
+           np.linspace(1.0, 2.0, Nev + 1)]
+    topl = M.StackedBrickTopology(rng, connectivity="full", rank=rank, size=size)
+    grid = M.DiscontinuousSpectralElementGrid(topl, N)
+    setup = A.CourantTestSetup(ps)
+    law = A.DryAtmosModel(setup, orientation=A.ORIENT_FLAT, ref_state=None, viscosity=2.0,
+                          dynamic_viscosity=True, sources=A.SRC_GRAVITY,
+                          boundary_conditions=(), param_set=ps)
+    return law, grid, setup
