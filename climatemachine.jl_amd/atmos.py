@@ -29,7 +29,8 @@ from .balancelaws import PHYSICS_DRY_ATMOS
 from .mesh import grids as G
 
 __all__ = ["PlanetParameters", "DryAtmosModel", "IsentropicVortexSetup", "HeldSuarezSetup",
-           "DecayingTemperatureProfile"]
+           "DecayingTemperatureProfile", "DryAdiabaticProfile", "RisingBubbleSetup",
+           "CourantTestSetup"]
 
 
 class PlanetParameters:
@@ -44,6 +45,7 @@ class PlanetParameters:
     MSLP = 1.01325e5
     day = 86400.0
     inv_Pr_turb = 3.0
+    C_smag = 0.21
 
     @property
     def R_d(self):
@@ -77,6 +79,50 @@ class DecayingTemperatureProfile:
         p = p / (H_sfc * (1 - dTvp ** 2))
         p = ps.MSLP * np.exp(p)
         return Tv, p
+
+
+class DryAdiabaticProfile:
+    """``DryAdiabaticProfile(T_surface, T_min_ref)`` of Thermodynamics.TemperatureProfiles
+    (Thermodynamics.jl 0.3.2, not vendored): ``T = max(T_surface - Gamma z, T_min)`` with
+    ``Gamma = g / cp_d``, ``p = MSLP (T / T_surface)^(g / (R_d Gamma))`` and an isothermal
+    decay above the height where ``T_min`` is reached."""
+
+    def __init__(self, ps, T_surface=300.0, T_min_ref=0.0):
+        self.ps, self.T_surface, self.T_min_ref = ps, T_surface, T_min_ref
+
+    def __call__(self, z):
+        ps = self.ps
+        Gamma = ps.grav / ps.cp_d
+        T = np.maximum(self.T_surface - Gamma * z, self.T_min_ref)
+        p = ps.MSLP * (T / self.T_surface) ** (ps.grav / (ps.R_d * Gamma))
+        if self.T_min_ref > 0:
+            z_top = (self.T_surface - self.T_min_ref) / Gamma
+            H_min = ps.R_d * self.T_min_ref / ps.grav
+            p = np.where(T == self.T_min_ref, p * np.exp(-(z - z_top) / H_min), p)
+        return T, p
+
+
+class RisingBubbleSetup:
+    """``init_risingbubble!`` of experiments/TestCase/risingbubble.jl:22-91 (dry)."""
+
+    def __init__(self, ps, theta_ref=300.0, xc=5000.0, zc=2000.0, rc=2000.0, theta_amplitude=2.0):
+        self.ps, self.theta_ref = ps, theta_ref
+        self.xc, self.zc, self.rc, self.amp = xc, zc, rc, theta_amplitude
+
+    def __call__(self, law, aux, coord, t):
+        ps = self.ps
+        x, z = coord[0], coord[2]
+        r = np.sqrt((x - self.xc) ** 2 + (z - self.zc) ** 2)
+        dtheta = np.where(r <= self.rc, self.amp * (1.0 - r / self.rc), 0.0)
+        theta = self.theta_ref + dtheta
+        pi_exner = 1.0 - ps.grav / (ps.cp_d * theta) * z
+        rho = ps.MSLP / (ps.R_d * theta) * pi_exner ** (ps.cv_d / ps.R_d)
+        T = theta * pi_exner
+        e_int = ps.cv_d * (T - ps.T_0)
+        e_pot = aux[:, law.off_phi, :]
+        rhoe = rho * (0.0 + e_pot + e_int)
+        zero = 0.0 * rho
+        return rho, [zero, zero, zero], rhoe
 
 
 class IsentropicVortexSetup:
@@ -177,14 +223,17 @@ BC_NONE, BC_ATMOS_DEFAULT = 0, 1
 
 class DryAtmosModel:
     """Dry compressible ``AtmosModel``: ``TotalEnergyModel``, ``DryModel``, constant
-    viscosity, optional hydrostatic reference state, ``DryBiharmonic`` hyperdiffusion,
-    sources ``Gravity / Coriolis / HeldSuarezForcing``."""
+    viscosity or ``SmagorinskyLilly(C_smag)``, optional hydrostatic reference state,
+    ``DryBiharmonic`` hyperdiffusion, sources ``Gravity / Coriolis / HeldSuarezForcing``."""
     physics_id = PHYSICS_DRY_ATMOS
 
     def __init__(self, init_state, orientation=ORIENT_SPHERICAL, ref_state=None,
                  subtract_off=True, viscosity=0.0, dynamic_viscosity=False,
                  hyperdiffusion_timescale=None, sources=0, boundary_conditions=(),
-                 param_set=None):
+                 param_set=None, smagorinsky=None):
+        self.C_smag = smagorinsky
+        if smagorinsky is not None:
+            assert hyperdiffusion_timescale is None and orientation != ORIENT_NONE
         self.ps = param_set or PlanetParameters()
         self.init_state = init_state
         self.orientation = orientation
@@ -202,13 +251,16 @@ class DryAtmosModel:
         o += 4 if has_or else 0
         self.off_ref = o
         o += 7 if has_ref else 0
+        has_smag = self.C_smag is not None
+        self.off_turb = o                      # turbulence.Delta (AtmosModel.jl:494-511 order)
+        o += 1 if has_smag else 0
         self.off_delta = o
         o += 1 if has_hyp else 0
         self.off_moist = o
         o += 2
         self.ns, self.naux = 5, o
-        self.ngrad = 4 + (4 if has_hyp else 0)
-        self.ngradflux = 9
+        self.ngrad = 4 + (1 if has_smag else 0) + (4 if has_hyp else 0)
+        self.ngradflux = 9 + (1 if has_smag else 0)
         self.ngradlap = 4 if has_hyp else 0
         self.nhyper = 12 if has_hyp else 0
 
@@ -224,12 +276,17 @@ class DryAtmosModel:
         ip[6] = len(self.boundary_conditions)
         for i, bc in enumerate(self.boundary_conditions):
             ip[7 + i] = bc
+        ip[14] = 1 if self.C_smag is not None else 0
         dp = np.zeros(32)
         dp[0] = self.viscosity
         dp[1] = self.tau_hyper if self.tau_hyper is not None else 0.0
         dp[2:13] = [ps.R_d, ps.cp_d, ps.cv_d, ps.T_0, ps.grav, ps.Omega, ps.MSLP, ps.day,
                     ps.planet_radius, ps.inv_Pr_turb, ps.kappa_d]
+        dp[13] = self.C_smag if self.C_smag is not None else 0.0
         return ip, dp
+
+    def state_names(self):
+        return ["ρ", "ρu[1]", "ρu[2]", "ρu[3]", "energy.ρe"]
 
     # -- init_state_auxiliary! (AtmosModel.jl:880-940) -------------------------------------
     def init_state_auxiliary(self, grid):
@@ -269,6 +326,16 @@ class DryAtmosModel:
             aux[:, o + 1, :] = p
             aux[:, o + 2, :] = T
             aux[:, o + 3, :] = rho * (0.0 + aux[:, self.off_phi, :] + ps.cv_d * (T - ps.T_0))
+        if self.C_smag is not None:
+            # init_aux_turbulence!: Delta = lengthscale(geom) = 2 / (cbrt(det(invJ)) max(N))
+            # (TurbulenceClosures.jl:431-438, Geometry.jl:121-122)
+            m = [[vg[:, c, :] for c in row] for row in (
+                (G._xi1x1, G._xi1x2, G._xi1x3), (G._xi2x1, G._xi2x2, G._xi2x3),
+                (G._xi3x1, G._xi3x2, G._xi3x3))]
+            det = (m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1])
+                   - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0])
+                   + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]))
+            aux[:, self.off_turb, :] = 2 / (np.cbrt(det) * max(max(1, n) for n in grid.N))
         if self.tau_hyper is not None:
             # lengthscale_horizontal (Geometry.jl:129-151): |dx/dxi_1|, |dx/dxi_2|
             N = grid.N

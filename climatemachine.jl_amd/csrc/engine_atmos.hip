@@ -6,11 +6,11 @@ namespace cmdg {
 
 int counts_atmos(const int32_t *ip, int32_t out[6])
 {
-    const bool orient = ip[0] != 0, ref = ip[1] != 0, hyp = ip[4] != 0;
+    const bool orient = ip[0] != 0, ref = ip[1] != 0, hyp = ip[4] != 0, smag = ip[14] == 1;
     out[0] = 5;
-    out[1] = 3 + (orient ? 4 : 0) + (ref ? 7 : 0) + (hyp ? 1 : 0) + 2;
-    out[2] = 4 + (hyp ? 4 : 0);
-    out[3] = 9;
+    out[1] = 3 + (orient ? 4 : 0) + (ref ? 7 : 0) + (smag ? 1 : 0) + (hyp ? 1 : 0) + 2;
+    out[2] = 4 + (smag ? 1 : 0) + (hyp ? 4 : 0);
+    out[3] = 9 + (smag ? 1 : 0);
     out[4] = hyp ? 4 : 0;
     out[5] = hyp ? 12 : 0;
     return CMDG_OK;
@@ -20,6 +20,15 @@ template <int NQ>
 static EngineBase *pick(const cmdg_desc *d, std::string &err)
 {
     const bool orient = d->iparam[0] != 0, ref = d->iparam[1] != 0, hyp = d->iparam[4] != 0;
+    if (d->iparam[14] == 1) {  // SmagorinskyLilly (AtmosLES configurations)
+        if (orient && ref && !hyp) return make_engine<DryAtmos<true, true, false, true>, NQ>(d);
+        err = "DryAtmos: SmagorinskyLilly is compiled with orientation + reference state, no hyperdiffusion";
+        return nullptr;
+    }
+    if (d->iparam[14] != 0) {
+        err = "DryAtmos: unknown turbulence closure";
+        return nullptr;
+    }
     if (!orient && !ref && !hyp) return make_engine<DryAtmos<false, false, false>, NQ>(d);
     if (orient && ref && hyp) return make_engine<DryAtmos<true, true, true>, NQ>(d);
     if (orient && ref && !hyp) return make_engine<DryAtmos<true, true, false>, NQ>(d);

@@ -337,16 +337,21 @@ RKC = (0.0, _f(1432997174477, 9575080441755), _f(2526269341429, 6820363962896),
 
 
 def lsrk54_step(dg, Q, dQ, t, dt, step_filter=None):
+    lsrk_step(dg, Q, dQ, t, dt, RKA, RKB, RKC, step_filter)
+
+
+def lsrk_step(dg, Q, dQ, t, dt, rka, rkb, rkc, step_filter=None):
     """``dostep!`` (LowStorageRungeKuttaMethod.jl:102-144): ``rhs!(dQ, Q, p, t + c dt,
     increment = true)`` then ``update!`` on the real elements.  ``step_filter`` =
     ``(filter, target, direction)`` applied to Q after the step (the every-step callback
     of experiments/AtmosGCM/heldsuarez.jl:261-272)."""
     nreal = dg.grid.nreal
     n = nreal * Q.shape[1] * Q.shape[2]
-    for s in range(5):
-        dg(dQ, Q, t + RKC[s] * dt, 1.0, 1.0)
-        lib().orc_lsrk_update(_p(dQ), _p(Q), C.c_double(RKA[(s + 1) % 5]),
-                              C.c_double(RKB[s]), C.c_double(dt), C.c_int64(n))
+    ns = len(rka)
+    for s in range(ns):
+        dg(dQ, Q, t + rkc[s] * dt, 1.0, 1.0)
+        lib().orc_lsrk_update(_p(dQ), _p(Q), C.c_double(rka[(s + 1) % ns]),
+                              C.c_double(rkb[s]), C.c_double(dt), C.c_int64(n))
     if step_filter is not None:
         f, tg, d = step_filter
         apply_filter(Q, tg, dg.grid, f, direction=d, state_auxiliary=dg.state_auxiliary)

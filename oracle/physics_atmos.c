@@ -8,7 +8,7 @@
  *   src/Atmos/Model/energy.jl:17-28,48-57, moisture.jl:47-62 (DryModel aux update)
  *   src/Atmos/Model/bc_momentum.jl:25-52, bc_energy.jl:10-20, boundaryconditions.jl:60-100
  *   src/Common/TurbulenceClosures/TurbulenceClosures.jl:354-420 (constant viscosity),
- *       :877-912 (DryBiharmonic)
+ *       :411-497 (SmagorinskyLilly), :877-912 (DryBiharmonic)
  *   experiments/AtmosGCM/heldsuarez.jl:106-172 (Held-Suarez forcing)
  * Thermodynamics.jl 0.3.2 / CLIMAParameters.jl 0.1.11 (not vendored in the reference):
  * dry closed forms, pinned by test/Numerics/DGMethods/Euler/isentropicvortex.jl:105.
@@ -19,7 +19,8 @@
  *   [4]=DryBiharmonic [5]=source bits (1 gravity, 2 coriolis, 4 Held-Suarez)
  *   [6]=nbc [7..13]=bc kind of tag 1..7 (1 = AtmosBC default: Impenetrable(FreeSlip), Insulating)
  *   dparam[0]=viscosity [1]=tau_hyper [2..12]=R_d cp_d cv_d T_0 grav Omega MSLP day
- *                                          planet_radius inv_Pr_turb kappa_d
+ *                                          planet_radius inv_Pr_turb kappa_d  [13]=C_smag
+ *   iparam[14]=turbulence closure (0 constant viscosity, 1 SmagorinskyLilly)
  */
 #include <math.h>
 #include <stdlib.h>
@@ -28,9 +29,9 @@
 #include "dg_oracle.h"
 
 typedef struct {
-    int orient, ref, subtract, kinematic, hyper, src, nbc, bc[8];
-    double visc, tau, R_d, cp_d, cv_d, T_0, grav, Omega, MSLP, day, a, invPr, kappa;
-    int oPhi, oRef, oDelta, oMoist;
+    int orient, ref, subtract, kinematic, hyper, src, nbc, bc[8], smag;
+    double visc, tau, R_d, cp_d, cv_d, T_0, grav, Omega, MSLP, day, a, invPr, kappa, C_smag;
+    int oPhi, oRef, oTurb, oDelta, oMoist;
 } atmos_t;
 
 /* ---- dry thermodynamics ------------------------------------------------------------ */
@@ -70,43 +71,68 @@ static void at_flux1(const void *p_, double *F, const double *Q, const double *a
     for (int d = 0; d < 3; ++d) F[d + 12] = u[d] * Q[4] + u[d] * p;
 }
 
-/* viscosity tensors: nu, D_t, tau = (-2 nu) S  (WithoutDivergence) */
-static void turbulence_tensors(const atmos_t *m, const double *Q, const double *gf, double *nu,
-                               double *Dt, double *tau /*6, compact lower*/)
-{
-    const double v = m->kinematic ? m->visc : m->visc / Q[0];
-    *nu = v;
-    *Dt = v * m->invPr;
-    for (int i = 0; i < 6; ++i) tau[i] = (-2 * v) * gf[3 + i];
-}
 static inline double sym(const double *c, int i, int j)
 { /* SHermitianCompact{3}: (1,1),(2,1),(3,1),(2,2),(3,2),(3,3) */
     static const int idx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
     return c[idx[i][j]];
 }
 
+/* turbulence_tensors: nu (diagonal), tau = (-2 nu) S as a full 3x3 (row d scaled by nu_d),
+ * tau[d + 3 c].  Constant viscosity: TurbulenceClosures.jl:372-408 (WithoutDivergence);
+ * SmagorinskyLilly: :476-497 */
+static void turbulence_tensors(const atmos_t *m, const double *Q, const double *gf,
+                               const double *aux, double *nu, double *tau)
+{
+    const double *S = gf + 3;
+    if (!m->smag) {
+        const double v = m->kinematic ? m->visc : m->visc / Q[0];
+        nu[0] = nu[1] = nu[2] = v;
+    } else {
+        /* strain_rate_magnitude(S) = sqrt(2 norm2(S)) (:268-285) */
+        const double norm2 = S[0] * S[0] + 2 * (S[1] * S[1]) + 2 * (S[2] * S[2]) + S[3] * S[3] +
+                             2 * (S[4] * S[4]) + S[5] * S[5];
+        const double normS = sqrt(2 * norm2);
+        double k[3];
+        for (int d = 0; d < 3; ++d) k[d] = aux[m->oPhi + 1 + d] / m->grav;
+        const double epsn = nextafter(fabs(normS), INFINITY) - fabs(normS); /* eps(normS) */
+        const double Ri = gf[9] / (normS * normS + epsn);
+        double c = 1.0 - Ri * m->invPr; /* clamp(.., 0, 1) */
+        c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+        const double fb2 = sqrt(c);
+        const double cd = m->C_smag * aux[m->oTurb];
+        const double nu0 = normS * (cd * cd) + 1e-5;
+        const double dk = nu0 * k[0] + nu0 * k[1] + nu0 * k[2]; /* dot(nu, k) */
+        for (int d = 0; d < 3; ++d) {
+            const double nv = k[d] * dk, nh = nu0 - nv;
+            nu[d] = nh + nv * fb2;
+        }
+    }
+    for (int d = 0; d < 3; ++d)
+        for (int c = 0; c < 3; ++c) tau[d + 3 * c] = (-2 * nu[d]) * sym(S, d, c);
+}
+
 static void at_flux2(const void *p_, double *F, const double *Q, const double *gf, const double *hyp,
                      const double *aux, double t)
 {
     const atmos_t *m = (const atmos_t *)p_;
-    (void)aux; (void)t;
-    double nu, Dt, tau[6];
-    turbulence_tensors(m, Q, gf, &nu, &Dt, tau);
+    (void)t;
+    double nu[3], tau[9];
+    turbulence_tensors(m, Q, gf, aux, nu, tau);
     const double rho = Q[0];
     /* Mass: no second-order tendencies for DryModel -> SVector(0,0,0) */
     for (int d = 0; d < 3; ++d) F[d] = 0.0;
     /* Momentum: ViscousStress (pad + tau*rho) [+ HyperdiffViscousFlux rho * nu grad^3 u_h] */
     for (int c = 0; c < 3; ++c)
         for (int d = 0; d < 3; ++d) {
-            double v = 0.0 + sym(tau, d, c) * rho;
+            double v = 0.0 + tau[d + 3 * c] * rho;
             if (m->hyper) v = v + rho * hyp[d + 3 * c];
             F[d + 3 * (1 + c)] = v;
         }
-    /* Energy: ViscousFlux tau*rho u, DiffEnthalpyFlux (-D_t grad h_tot) rho
+    /* Energy: ViscousFlux tau*rho u, DiffEnthalpyFlux (-D_t .* grad h_tot) rho
        [+ HyperdiffEnthalpyFlux nu grad^3 h_tot * rho + HyperdiffViscousFlux nu grad^3 u_h * rho u] */
     for (int d = 0; d < 3; ++d) {
-        double v = (sym(tau, d, 0) * Q[1] + sym(tau, d, 1) * Q[2] + sym(tau, d, 2) * Q[3]) +
-                   (-Dt * gf[d]) * rho;
+        const double Dt = nu[d] * m->invPr;
+        double v = (tau[d] * Q[1] + tau[d + 3] * Q[2] + tau[d + 6] * Q[3]) + (-Dt * gf[d]) * rho;
         if (m->hyper) {
             v = v + hyp[9 + d] * rho;
             v = v + (hyp[d + 0] * Q[1] + hyp[d + 3] * Q[2] + hyp[d + 6] * Q[3]);
@@ -193,6 +219,7 @@ static void at_gradarg(const void *p_, double *G, const double *Q, const double 
     const double T = air_T(m, internal_energy(m, Q, aux));
     const double e_tot = Q[4] * (1 / Q[0]);
     G[3] = e_tot + m->R_d * T;
+    if (m->smag) G[4] = aux[m->oMoist]; /* transform.turbulence.theta_v = aux.moisture.theta_v */
     if (m->hyper) {
         double u[3], k[3];
         for (int d = 0; d < 3; ++d) u[d] = Q[1 + d] * rhoinv;
@@ -212,7 +239,11 @@ static void at_gradarg(const void *p_, double *G, const double *Q, const double 
 static void at_gradflux(const void *p_, double *gf, const double *g, const double *Q, const double *aux,
                         double t)
 {
-    (void)p_; (void)Q; (void)aux; (void)t;
+    const atmos_t *m = (const atmos_t *)p_;
+    (void)Q; (void)t;
+    if (m->smag) /* N^2 = dot(grad theta_v, grad Phi) / aux.moisture.theta_v  (:451-466) */
+        gf[9] = (g[0 + 3 * 4] * aux[m->oPhi + 1] + g[1 + 3 * 4] * aux[m->oPhi + 2] +
+                 g[2 + 3 * 4] * aux[m->oPhi + 3]) / aux[m->oMoist];
     /* energy: grad h_tot ; turbulence: S = symmetrize(grad u) */
     for (int d = 0; d < 3; ++d) gf[d] = g[d + 3 * 3];
     /* grad u is 3x3 with g[d + 3*c] = d u_c / d x_d ; symmetrize(A) = (A + A')/2 lower */
@@ -304,10 +335,23 @@ static double at_courant(const void *p_, int kind, const double *Q, const double
     double k[3] = {0, 0, 0};
     if (m->orient)
         for (int d = 0; d < 3; ++d) k[d] = aux[m->oPhi + 1 + d] / m->grav;
-    if (kind == 2) { /* diffusive_courant: nu is a scalar for the constant-viscosity closures */
-        double nu, Dt, tau[6];
-        turbulence_tensors(m, Q, gf, &nu, &Dt, tau);
-        return dt * nu / (dx * dx);
+    if (kind == 2) { /* diffusive_courant: norm_nu (courant.jl:19-24) */
+        double nu[3], tau[9], normnu;
+        turbulence_tensors(m, Q, gf, aux, nu, tau);
+        if (!m->smag) {
+            normnu = nu[0]; /* nu::Real */
+        } else {
+            const double dk = nu[0] * k[0] + nu[1] * k[1] + nu[2] * k[2];
+            if (direction == ORC_VERTICAL) {
+                normnu = dk;
+            } else {
+                double v[3];
+                for (int d = 0; d < 3; ++d)
+                    v[d] = direction == ORC_HORIZONTAL ? nu[d] - dk * k[d] : nu[d];
+                normnu = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            }
+        }
+        return dt * normnu / (dx * dx);
     }
     double normu;
     const double dotk = Q[1] * k[0] + Q[2] * k[1] + Q[3] * k[2];
@@ -338,18 +382,21 @@ orc_physics *orc_atmos_new(const int *ip, const double *dp, int nf_first)
     m->R_d = dp[2]; m->cp_d = dp[3]; m->cv_d = dp[4]; m->T_0 = dp[5]; m->grav = dp[6];
     m->Omega = dp[7]; m->MSLP = dp[8]; m->day = dp[9]; m->a = dp[10]; m->invPr = dp[11];
     m->kappa = dp[12];
+    m->C_smag = dp[13];
+    m->smag = ip[14] == 1;
     int o = 3;
     m->oPhi = o;   o += m->orient ? 4 : 0;
     m->oRef = o;   o += m->ref ? 7 : 0;
+    m->oTurb = o;  o += m->smag ? 1 : 0;
     m->oDelta = o; o += m->hyper ? 1 : 0;
     m->oMoist = o; o += 2;
     ph->ns = 5;
     ph->naux = o;
-    ph->ngrad = 4 + (m->hyper ? 4 : 0);
-    ph->ngf = 9;
+    ph->ngrad = 4 + (m->smag ? 1 : 0) + (m->hyper ? 4 : 0);
+    ph->ngf = 9 + (m->smag ? 1 : 0);
     ph->ngl = m->hyper ? 4 : 0;
     ph->nhyp = m->hyper ? 12 : 0;
-    for (int s = 0; s < 4; ++s) ph->hv_indexmap[s] = 4 + s;
+    for (int s = 0; s < 4; ++s) ph->hv_indexmap[s] = 4 + (m->smag ? 1 : 0) + s;
     ph->nf_first = nf_first;
     ph->p = m;
     ph->flux_first_order = at_flux1;

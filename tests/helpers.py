@@ -101,3 +101,29 @@ def courant_test_setup(Neh=10, Nev=4, N=4, rank=0, size=1):
                           dynamic_viscosity=True, sources=A.SRC_GRAVITY,
                           boundary_conditions=(), param_set=ps)
     return law, grid, setup
+
+
+def rising_bubble_setup(nx=20, ny=1, nz=20, N=4, rank=0, size=1):
+    """experiments/TestCase/risingbubble.jl:93-132,186-200 through AtmosLESConfiguration
+    (src/Driver/driver_configs.jl:190-290): stacked brick [0,10 km] x [0,500 m] x [0,10 km]
+    with 500 m elements (resolution 125 m x N = 4), periodic in x and y, boundary (1, 2) in
+    z with the default AtmosBC, FlatOrientation, HydrostaticState(DryAdiabaticProfile(300 K)),
+    SmagorinskyLilly(C_smag), DryModel, Gravity; Rusanov + central fluxes.
+    BASELINE config 2 is the same setup at 20 x 20 x 20 elements."""
+    A = cm.atmos
+    ps = A.PlanetParameters()
+    rng = [np.linspace(0.0, 500.0 * nx, nx + 1), np.linspace(0.0, 500.0 * ny, ny + 1),
+           np.linspace(0.0, 500.0 * nz, nz + 1)]
+    topl = M.StackedBrickTopology(rng, periodicity=(True, True, False),
+                                  boundary=((0, 0), (0, 0), (1, 2)), rank=rank, size=size)
+    grid = M.DiscontinuousSpectralElementGrid(topl, N)
+    # the reference's bubble (centre 5 km, 2 km; radius 2 km) on the full 10 km domain; scaled
+    # with the domain on the reduced meshes of the tests so that it stays inside
+    Lx, Lz = 500.0 * nx, 500.0 * nz
+    setup = A.RisingBubbleSetup(ps, xc=Lx / 2, zc=Lz / 5, rc=Lx / 5)
+    law = A.DryAtmosModel(setup, orientation=A.ORIENT_FLAT,
+                          ref_state=A.DryAdiabaticProfile(ps, 300.0, 0.0),
+                          smagorinsky=ps.C_smag, sources=A.SRC_GRAVITY,
+                          boundary_conditions=(A.BC_ATMOS_DEFAULT, A.BC_ATMOS_DEFAULT),
+                          param_set=ps)
+    return law, grid
