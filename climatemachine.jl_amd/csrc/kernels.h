@@ -19,8 +19,10 @@
 #ifndef CMDG_TEND_MINW
 #define CMDG_TEND_MINW 1
 #endif
+// k_gradients: the Held-Suarez instantiation needs 130 VGPRs unconstrained (3 waves/SIMD);
+// asking for 4 gives 128 without scratch and 9 % less time per launch (profiles/r01_ab_*.txt)
 #ifndef CMDG_GRAD_MINW
-#define CMDG_GRAD_MINW 1
+#define CMDG_GRAD_MINW 4
 #endif
 #ifndef CMDG_LAP_MINW
 #define CMDG_LAP_MINW 1
