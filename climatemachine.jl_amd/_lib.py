@@ -9,7 +9,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMDG_LIB", os.path.join(_HERE, "libcmdg.so"))   # CMDG_LIB: tuning builds
 
 CMDG_K = dict(GRADIENTS=0, DIVGRAD=1, GRADLAP=2, TENDENCY=3, PACK=4, UNPACK=5, UPDATE_AUX=6,
-              FILTER=7)
+              FILTER=7, STACK_INTEGRAL=8)
+STACK_MAXOUT = 8
+
+
+class CmdgStackIntegralDesc(C.Structure):
+    """``cmdg_stack_integral_desc`` of include/cmdg.h."""
+    _fields_ = [
+        ("nout", C.c_int32),
+        ("src_is_state", C.c_int32 * STACK_MAXOUT), ("src_col", C.c_int32 * STACK_MAXOUT),
+        ("scale", C.c_double * STACK_MAXOUT), ("dst_col", C.c_int32 * STACK_MAXOUT),
+        ("rsrc_col", C.c_int32 * STACK_MAXOUT), ("rdst_col", C.c_int32 * STACK_MAXOUT),
+    ]
 
 
 class CmdgDesc(C.Structure):
@@ -61,6 +72,8 @@ SYMBOLS = [
     ("cmdg_distance2_local", C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     ("cmdg_courant", C.c_int, [_vp, _i32, _vp, _d, _d, _i32, _vp]),
     ("cmdg_min_node_distance", C.c_int, [_vp, _i32, _vp]),
+    ("cmdg_indefinite_stack_integral", C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    ("cmdg_reverse_indefinite_stack_integral", C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     ("cmdg_filter_create", C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     ("cmdg_filter_destroy", C.c_int, [_vp, _vp]),
     ("cmdg_filter_apply", C.c_int, [_vp, _vp, _vp, _i32]),

@@ -8,6 +8,7 @@
 
 #include "engine.h"
 #include "filters.h"
+#include "columns.h"
 
 namespace cmdg {
 
@@ -83,6 +84,7 @@ EngineBase::~EngineBase()
     if (derived) hipFree(derived);
     if (d_partial) hipFree(d_partial);
     if (d_elemred) hipFree(d_elemred);
+    if (d_Imat) hipFree(d_Imat);
     if (ev_comp) hipEventDestroy(ev_comp);
     if (nccl_comm && rccl::CommDestroy) rccl::CommDestroy(nccl_comm);
     if (s_comp) hipStreamDestroy(s_comp);
@@ -481,6 +483,77 @@ int EngineBase::courant(int mode, int kind, const double *Q, double dt, double t
                        d_elemred + nreal);
     HIPCHK(hipMemcpyAsync(out, d_elemred + nreal, sizeof(double), hipMemcpyDeviceToHost, s_comp));
     HIPCHK(hipStreamSynchronize(s_comp));
+    return CMDG_OK;
+}
+
+// ---- indefinite_stack_integral! / reverse_indefinite_stack_integral!  DGModel.jl:445-529 ----
+template <int NQ_, int NOUT>
+static void launch_stack(bool reverse, const StackArgs &a, hipStream_t st)
+{
+    constexpr int SPB = 256 / (NQ_ * NQ_);
+    const dim3 grid((unsigned)((a.nhorz + SPB - 1) / SPB)), block(256);
+    if (reverse)
+        hipLaunchKernelGGL((k_reverse_stack_integral<NQ_, NOUT>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((k_stack_integral<NQ_, NOUT>), grid, block, 0, st, a);
+}
+
+int EngineBase::stack_integral(bool reverse, const double *Q, int nstate, double *aux_arr,
+                               int naux_arr, int nvert, const double *Imat_host,
+                               const cmdg_stack_integral_desc *d)
+{
+    if (NQ != 5) return fail(CMDG_ERR_UNSUPPORTED, "stack integral: polynomial order not compiled in");
+    if (!stacked) return fail(CMDG_ERR_INVALID, "stack integral: the topology is not stacked");
+    if (nvert < 1 || nreal % nvert != 0)
+        return fail(CMDG_ERR_INVALID, "stack integral: nreal is not a multiple of nvertelem");
+    if (d->nout < 1 || d->nout > CMDG_STACK_MAXOUT) return fail(CMDG_ERR_INVALID, "stack integral: nout");
+    if (g.nvgeo < 16) return fail(CMDG_ERR_INVALID, "stack integral: vgeo lacks the JcV column");
+    for (int s = 0; s < d->nout; ++s) {
+        const bool st = !reverse && d->src_is_state[s] != 0;
+        const int src = reverse ? d->rsrc_col[s] : d->src_col[s];
+        const int dst = reverse ? d->rdst_col[s] : d->dst_col[s];
+        if (st && !Q) return fail(CMDG_ERR_INVALID, "stack integral: state integrand without Q");
+        if (src < 0 || src >= (st ? nstate : naux_arr) || dst < 0 || dst >= naux_arr)
+            return fail(CMDG_ERR_INVALID, "stack integral: column out of range");
+    }
+    if (nreal == 0) return CMDG_OK;
+    if (!reverse) {
+        if (!Imat_host) return fail(CMDG_ERR_INVALID, "stack integral: Imat is NULL");
+        if (!d_Imat) HIPCHK(hipMalloc(&d_Imat, sizeof(double) * NQ * NQ));
+        HIPCHK(hipMemcpyAsync(d_Imat, Imat_host, sizeof(double) * NQ * NQ, hipMemcpyHostToDevice, s_comp));
+        HIPCHK(hipStreamSynchronize(s_comp));  // Imat_host may be a temporary of the caller
+    }
+    StackArgs a{};
+    a.Q = Q;
+    a.aux = aux_arr;
+    a.vgeo = g.vgeo;
+    a.Imat = d_Imat;
+    a.nstate = nstate;
+    a.naux = naux_arr;
+    a.nvgeo = g.nvgeo;
+    a.nvert = nvert;
+    a.jcv = 15;  // _JcV (Grids.jl:76-92)
+    a.nhorz = nreal / nvert;
+    // integrals of different variables are independent: four ride in one launch
+    for (int c0 = 0; c0 < d->nout; c0 += 4) {
+        const int n = std::min(4, d->nout - c0);
+        for (int s = 0; s < n; ++s) {
+            a.is_state[s] = reverse ? 0 : d->src_is_state[c0 + s];
+            a.src[s] = reverse ? d->rsrc_col[c0 + s] : d->src_col[c0 + s];
+            a.dst[s] = reverse ? d->rdst_col[c0 + s] : d->dst_col[c0 + s];
+            a.scale[s] = d->scale[c0 + s];
+        }
+        prof_begin(CMDG_K_STACK_INTEGRAL, s_comp);
+        switch (n) {
+        case 1: launch_stack<5, 1>(reverse, a, s_comp); break;
+        case 2: launch_stack<5, 2>(reverse, a, s_comp); break;
+        case 3: launch_stack<5, 3>(reverse, a, s_comp); break;
+        default: launch_stack<5, 4>(reverse, a, s_comp); break;
+        }
+        prof_end(s_comp);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CMDG_ERR_HIP, std::string("stack integral launch: ") + hipGetErrorString(e));
     return CMDG_OK;
 }
 
@@ -914,6 +987,21 @@ int cmdg_min_node_distance(cmdg_handle h, int32_t direction, double *out_host)
 {
     if (!h || !out_host) return CMDG_ERR_INVALID;
     return set_err(h, h->eng->courant(0, 0, nullptr, 0.0, 0.0, direction, out_host));
+}
+
+int cmdg_indefinite_stack_integral(cmdg_handle h, const double *Q, int32_t nstate, double *aux,
+                                   int32_t naux, int32_t nvertelem, const double *Imat,
+                                   const cmdg_stack_integral_desc *d)
+{
+    if (!h || !aux || !d || naux < 1) return CMDG_ERR_INVALID;
+    return set_err(h, h->eng->stack_integral(false, Q, nstate, aux, naux, nvertelem, Imat, d));
+}
+
+int cmdg_reverse_indefinite_stack_integral(cmdg_handle h, double *aux, int32_t naux,
+                                           int32_t nvertelem, const cmdg_stack_integral_desc *d)
+{
+    if (!h || !aux || !d || naux < 1) return CMDG_ERR_INVALID;
+    return set_err(h, h->eng->stack_integral(true, nullptr, 0, aux, naux, nvertelem, nullptr, d));
 }
 
 int cmdg_filter_create(cmdg_handle h, const cmdg_filter_desc *d, cmdg_filter *out)

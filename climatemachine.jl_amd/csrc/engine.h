@@ -122,6 +122,9 @@ struct EngineBase {
     int wsum2(const double *A, const double *B, int nvar, int weighted, double *out);
     int courant(int mode, int kind, const double *Q, double dt, double t, int dir, double *out);
     double *d_elemred = nullptr;  // (nreal) per-element extrema
+    int stack_integral(bool reverse, const double *Q, int nstate, double *aux_arr, int naux_arr,
+                       int nvert, const double *Imat_host, const cmdg_stack_integral_desc *d);
+    double *d_Imat = nullptr;
     int filter_create(const cmdg_filter_desc *d, FilterObj **out);
     int filter_apply(const FilterObj *f, double *Q, int nstate);
 

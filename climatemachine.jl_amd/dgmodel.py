@@ -189,6 +189,41 @@ class DGModel:
         """``calculate_dt(dg, model, Q, Courant_number, t, direction)`` (DGMethods.jl:79-83)."""
         return courant_number / self.courant(NONDIFFUSIVE_COURANT, Q, 1.0, t, direction)
 
+    # -- column integrals (DGModel.jl:445-529) -----------------------------------------------
+    def _stack_desc(self, src, scale, dst, rsrc, rdst):
+        d = _lib.CmdgStackIntegralDesc()
+        d.nout = len(dst) if dst else len(rdst)
+        for s in range(d.nout):
+            if src:
+                d.src_is_state[s], d.src_col[s] = int(src[s][0]), int(src[s][1])
+                d.scale[s] = float(scale[s]) if scale else 1.0
+                d.dst_col[s] = int(dst[s])
+            if rsrc:
+                d.rsrc_col[s], d.rdst_col[s] = int(rsrc[s]), int(rdst[s])
+        return d
+
+    def indefinite_stack_integral(self, Q, aux, src, dst, scale=None):
+        """``indefinite_stack_integral!(dg, m, Q, state_auxiliary, t)``: the upward integral
+        of ``scale_s * field_s`` (``src = [(is_state, column), ...]``, 0-based) along every
+        stack of elements goes to auxiliary column ``dst[s]``."""
+        g = self.grid
+        Imat = np.ascontiguousarray(np.asarray(g.Imat[-1], dtype=np.float64).T)
+        d = self._stack_desc(src, scale, dst, None, None)
+        self._torch_ready()
+        _lib.check(self.L.cmdg_indefinite_stack_integral(
+            self.handle, Q.data_ptr() if Q is not None else None,
+            Q.shape[1] if Q is not None else 0, aux.data_ptr(), aux.shape[1],
+            int(g.topology.stacksize), Imat.ctypes.data, C.byref(d)), self.handle)
+
+    def reverse_indefinite_stack_integral(self, aux, rsrc, rdst):
+        """``reverse_indefinite_stack_integral!``: auxiliary column ``rdst[s]`` receives
+        (value of column ``rsrc[s]`` at the top of the stack) - (its value at the node)."""
+        d = self._stack_desc(None, None, None, rsrc, rdst)
+        self._torch_ready()
+        _lib.check(self.L.cmdg_reverse_indefinite_stack_integral(
+            self.handle, aux.data_ptr(), aux.shape[1], int(self.grid.topology.stacksize),
+            C.byref(d)), self.handle)
+
     def set_filters(self, gradient_filter=None, tendency_filter=None, step_filter=None):
         """``DGModel(...; gradient_filter, tendency_filter)`` (DGModel.jl:44-45, applied at
         :185-193 and :417-425) and the every-step user filter callback of

@@ -291,6 +291,23 @@ def computegeometry(elemtocoord, D, xi, omega, meshwarp=None):
     return vgeo, sgeo
 
 
+def indefinite_integral_interpolation_matrix(r, omega):
+    """Reference: Grids.jl:1184-1207.  ``I @ f(r)`` is the indefinite integral (from ``r[0]``)
+    of the interpolant of ``f``, evaluated at the points ``r``."""
+    r = np.asarray(r, dtype=np.float64)
+    omega = np.asarray(omega, dtype=np.float64)
+    Nq = len(r)
+    I = np.zeros((Nq, Nq))
+    I[0, :] = omega[0] if Nq == 1 else 0.0
+    wbary = elements.baryweights(r)
+    for n in range(1, Nq):
+        rdst = (1 - r) / 2 * r[0] + (1 + r) / 2 * r[n]
+        In = elements.interpolationmatrix(r, rdst, wbary)
+        delta = (r[n] - r[0]) / 2
+        I[n, :] = delta * (omega @ In)
+    return I
+
+
 class DiscontinuousSpectralElementGrid:
     """Reference: Grids.jl:170-413.  ``polynomialorder`` is an int or a tuple
     (a 2-tuple in 3-D means (horizontal, vertical))."""
@@ -322,6 +339,8 @@ class DiscontinuousSpectralElementGrid:
         self.xi = [p[0] for p in xw]
         self.omega = [p[1] for p in xw]
         self.D = [elements.spectralderivative(x) for x in self.xi]
+        self.Imat = [indefinite_integral_interpolation_matrix(x, w)
+                     for x, w in zip(self.xi, self.omega)]
         self.vgeo, self.sgeo = computegeometry(t.elemtocoord, self.D, self.xi,
                                                self.omega, meshwarp)
         act = np.zeros(self.Np * t.nelem, dtype=bool)

@@ -167,6 +167,31 @@ int cmdg_courant(cmdg_handle h, int32_t kind, const double *Q, double dt, double
  * rank; the caller applies MPI.Allreduce(min). */
 int cmdg_min_node_distance(cmdg_handle h, int32_t direction, double *out_host);
 
+/* ---- column (stack) integrals ------------------------------------------------------ */
+/* indefinite_stack_integral! / reverse_indefinite_stack_integral! (DGModel.jl:445-529, kernels
+ * DGModel_kernels.jl:1903-2104) on stacked topologies (elements of a stack contiguous,
+ * e = ev + (eh - 1) nvertelem).  The law's integral_load/set_auxiliary_state! hooks are
+ * carried as a field combination: integrand_s = scale_s * field_s, where field_s is column
+ * src_col[s] (0-based) of the prognostic state (src_is_state[s] != 0) or of the auxiliary
+ * array; the upward integral goes to auxiliary column dst_col[s]; the reverse integral reads
+ * auxiliary column rsrc_col[s] and writes (value at the top of the stack) - value to rdst_col[s]. */
+#define CMDG_STACK_MAXOUT 8
+typedef struct cmdg_stack_integral_desc {
+    int32_t nout; /* 1..CMDG_STACK_MAXOUT */
+    int32_t src_is_state[CMDG_STACK_MAXOUT], src_col[CMDG_STACK_MAXOUT];
+    double scale[CMDG_STACK_MAXOUT];
+    int32_t dst_col[CMDG_STACK_MAXOUT];
+    int32_t rsrc_col[CMDG_STACK_MAXOUT], rdst_col[CMDG_STACK_MAXOUT];
+} cmdg_stack_integral_desc;
+/* Q (Np, nstate, nelem) may be NULL when no integrand reads the state; aux (Np, naux, nelem) is
+ * updated in place on the real elements; Imat = HOST (Nq, Nq) column-major grid.Imat[dim]
+ * (Grids.jl:1184-1207).  Enqueued on the compute stream. */
+int cmdg_indefinite_stack_integral(cmdg_handle h, const double *Q, int32_t nstate, double *aux,
+                                   int32_t naux, int32_t nvertelem, const double *Imat,
+                                   const cmdg_stack_integral_desc *d);
+int cmdg_reverse_indefinite_stack_integral(cmdg_handle h, double *aux, int32_t naux,
+                                           int32_t nvertelem, const cmdg_stack_integral_desc *d);
+
 /* ---- element filters (src/Numerics/Mesh/Filters.jl) ------------------------------ */
 typedef struct cmdg_filter_s *cmdg_filter;
 /* AbstractFilter: spectral = Exponential / BoydVandeven / Cutoff (Filters.jl:172-307,
@@ -213,7 +238,7 @@ int cmdg_set_filters(cmdg_handle h, cmdg_filter gradient_filter, cmdg_filter ten
 enum {
     CMDG_K_GRADIENTS = 0, CMDG_K_DIVGRAD = 1, CMDG_K_GRADLAP = 2, CMDG_K_TENDENCY = 3,
     CMDG_K_PACK = 4, CMDG_K_UNPACK = 5, CMDG_K_UPDATE_AUX = 6, CMDG_K_FILTER = 7,
-    CMDG_K_COUNT = 8
+    CMDG_K_STACK_INTEGRAL = 8, CMDG_K_COUNT = 9
 };
 /* bracket every launch with HIP events on the launch stream (off by default) */
 int cmdg_profile_enable(cmdg_handle h, int32_t on);

@@ -137,6 +137,35 @@ void orc_min_neighbor_distance(const orc_grid *g, int direction, double *out);
 void orc_local_courant(const orc_physics *ph, const orc_grid *g, int kind, double *pointwise,
                        const double *Q, const double *aux, const double *gf, double dt,
                        double simtime, int direction);
+/* ---- column (stack) integrals: DGModel_kernels.jl:1903-2104 ------------------------- */
+/* integral_load/set_auxiliary_state!, reverse_integral_load/set_auxiliary_state! of a law
+ * (BalanceLaws/interface.jl) */
+typedef struct orc_integral_law {
+    int nout, nrout; /* UpwardIntegrals / DownwardIntegrals variables */
+    int ns, naux;
+    const void *p;
+    void (*load)(const void *p, double *integrand, const double *Q, const double *aux);
+    void (*set)(const void *p, double *aux, const double *integral);
+    void (*rload)(const void *p, double *integral, const double *Q, const double *aux);
+    void (*rset)(const void *p, double *aux, const double *integral);
+} orc_integral_law;
+/* kernel_indefinite_stack_integral! over horizontal elements [h0, h1) (0-based); Imat is the
+ * (Nq3, Nq3) column-major grid.Imat[dim]; JcV = 0-based vgeo column of _JcV */
+void orc_indefinite_stack_integral(const orc_integral_law *law, const orc_grid *g, int nvertelem,
+                                   const double *Q, double *aux, const double *Imat, int JcV,
+                                   int64_t h0, int64_t h1);
+/* kernel_reverse_indefinite_stack_integral! (Nq3 > 1) */
+void orc_reverse_indefinite_stack_integral(const orc_integral_law *law, const orc_grid *g,
+                                           int nvertelem, const double *Q, double *aux,
+                                           int64_t h0, int64_t h1);
+/* the reference's IntegralTestModel{3} (test/Numerics/DGMethods/integral_test.jl:37-140) and
+ * the field-combination law that mirrors cmdg_stack_integral_desc */
+orc_integral_law *orc_integral_test_law(void);
+orc_integral_law *orc_integral_fields_law(int nout, const int *src_is_state, const int *src_col,
+                                          const double *scale, const int *dst_col,
+                                          const int *rsrc_col, const int *rdst_col, int ns,
+                                          int naux);
+void orc_integral_law_free(orc_integral_law *law);
 /* ---- element filters (filter_oracle.c) ------------------------------------------- */
 /* filter target: kind 0 FilterIndices (idx 1-based), 1 AtmosFilterPerturbations,
  * 2 AtmosSpecificFilterPerturbations (aux_ref_*: 0-based aux columns of ref_state.rho, .rho e) */

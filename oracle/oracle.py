@@ -412,6 +412,53 @@ def calculate_dt(dg, Q, courant_number, t=0.0, direction=EVERY):
     return courant_number / courant(NONDIFFUSIVE_COURANT, dg, Q, 1.0, t, direction)
 
 
+# ---- column (stack) integrals (integral_oracle.c) ---------------------------------------
+class _IntegralLaw(C.Structure):
+    _fields_ = [("nout", C.c_int), ("nrout", C.c_int), ("ns", C.c_int), ("naux", C.c_int),
+                ("p", C.c_void_p), ("load", C.c_void_p), ("set", C.c_void_p),
+                ("rload", C.c_void_p), ("rset", C.c_void_p)]
+
+
+def integral_test_law():
+    """``IntegralTestModel{3}`` of test/Numerics/DGMethods/integral_test.jl."""
+    L = lib()
+    L.orc_integral_test_law.restype = C.POINTER(_IntegralLaw)
+    return L.orc_integral_test_law()
+
+
+def integral_fields_law(src, scale, dst, rsrc, rdst, ns, naux):
+    """Integrands ``scale_s * field_s`` with ``src = [(is_state, column), ...]``; forward
+    integrals go to aux columns ``dst``, reverse integrals read ``rsrc`` and write ``rdst``."""
+    L = lib()
+    L.orc_integral_fields_law.restype = C.POINTER(_IntegralLaw)
+    n = len(src)
+    ia = lambda v: (C.c_int * n)(*[int(x) for x in v])
+    return L.orc_integral_fields_law(n, ia([s[0] for s in src]), ia([s[1] for s in src]),
+                                     (C.c_double * n)(*[float(x) for x in scale]), ia(dst),
+                                     ia(rsrc), ia(rdst), int(ns), int(naux))
+
+
+def indefinite_stack_integral(law, og, Q, aux, horzelems=None):
+    """``indefinite_stack_integral!(dg, m, Q, state_auxiliary, t, elems)`` (DGModel.jl:445-487)."""
+    g = og.grid
+    nv = g.topology.stacksize
+    h0, h1 = (0, g.nreal // nv) if horzelems is None else horzelems
+    Imat = np.ascontiguousarray(np.asarray(g.Imat[-1], dtype=np.float64).T)     # column-major
+    Qp = _p(Q) if Q is not None and Q.size else None
+    lib().orc_indefinite_stack_integral(law, C.byref(og.c), int(nv), Qp, _p(aux), _p(Imat),
+                                        15, C.c_int64(h0), C.c_int64(h1))
+
+
+def reverse_indefinite_stack_integral(law, og, Q, aux, horzelems=None):
+    """``reverse_indefinite_stack_integral!`` (DGModel.jl:489-529)."""
+    g = og.grid
+    nv = g.topology.stacksize
+    h0, h1 = (0, g.nreal // nv) if horzelems is None else horzelems
+    Qp = _p(Q) if Q is not None and Q.size else None
+    lib().orc_reverse_indefinite_stack_integral(law, C.byref(og.c), int(nv), Qp, _p(aux),
+                                                C.c_int64(h0), C.c_int64(h1))
+
+
 # ---- element filters (filter_oracle.c) --------------------------------------------------
 class _FilterTarget(C.Structure):
     _fields_ = [("kind", C.c_int), ("nfs", C.c_int), ("idx", C.c_int * MAXS),

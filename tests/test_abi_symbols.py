@@ -68,3 +68,10 @@ def test_filter_desc_struct_matches_header_field_order():
     assert fields == [f[0] for f in F.CmdgFilterDesc._fields_], fields
     txt = open(os.path.join(ROOT, "include", "cmdg.h")).read()
     assert "#define CMDG_MAX_FILTER_STATES %d" % F.MAX_FILTER_STATES in txt
+
+
+def test_stack_integral_desc_struct_matches_header_field_order():
+    fields = _header_fields("cmdg_stack_integral_desc")
+    assert fields == [f[0] for f in cm._lib.CmdgStackIntegralDesc._fields_], fields
+    txt = open(os.path.join(ROOT, "include", "cmdg.h")).read()
+    assert "#define CMDG_STACK_MAXOUT %d" % cm._lib.STACK_MAXOUT in txt
