@@ -502,7 +502,7 @@ int EngineBase::stack_integral(bool reverse, const double *Q, int nstate, double
                                int naux_arr, int nvert, const double *Imat_host,
                                const cmdg_stack_integral_desc *d)
 {
-    if (NQ != 5) return fail(CMDG_ERR_UNSUPPORTED, "stack integral: polynomial order not compiled in");
+    if (NQ < 2 || NQ > 8) return fail(CMDG_ERR_UNSUPPORTED, "stack integral: polynomial order not compiled in");
     if (!stacked) return fail(CMDG_ERR_INVALID, "stack integral: the topology is not stacked");
     if (nvert < 1 || nreal % nvert != 0)
         return fail(CMDG_ERR_INVALID, "stack integral: nreal is not a multiple of nvertelem");
@@ -544,12 +544,21 @@ int EngineBase::stack_integral(bool reverse, const double *Q, int nstate, double
             a.scale[s] = d->scale[c0 + s];
         }
         prof_begin(CMDG_K_STACK_INTEGRAL, s_comp);
-        switch (n) {
-        case 1: launch_stack<5, 1>(reverse, a, s_comp); break;
-        case 2: launch_stack<5, 2>(reverse, a, s_comp); break;
-        case 3: launch_stack<5, 3>(reverse, a, s_comp); break;
-        default: launch_stack<5, 4>(reverse, a, s_comp); break;
+#define CMDG_STACK_CASE(Q)                                          \
+    case Q:                                                         \
+        switch (n) {                                                \
+        case 1: launch_stack<Q, 1>(reverse, a, s_comp); break;      \
+        case 2: launch_stack<Q, 2>(reverse, a, s_comp); break;      \
+        case 3: launch_stack<Q, 3>(reverse, a, s_comp); break;      \
+        default: launch_stack<Q, 4>(reverse, a, s_comp); break;     \
+        }                                                           \
+        break;
+        switch (NQ) {
+            CMDG_STACK_CASE(2) CMDG_STACK_CASE(3) CMDG_STACK_CASE(4) CMDG_STACK_CASE(5)
+            CMDG_STACK_CASE(6) CMDG_STACK_CASE(7) CMDG_STACK_CASE(8)
+        default: break;
         }
+#undef CMDG_STACK_CASE
         prof_end(s_comp);
     }
     hipError_t e = hipGetLastError();
@@ -622,10 +631,25 @@ static void launch_filter(const FilterObj *f, const FilterArgs &a, int nfs, int6
     }
 }
 
+static void launch_filter_nq(int NQ, const FilterObj *f, const FilterArgs &a, int nfs,
+                             int64_t nreal, hipStream_t st)
+{
+    switch (NQ) {
+    case 2: launch_filter<2>(f, a, nfs, nreal, st); break;
+    case 3: launch_filter<3>(f, a, nfs, nreal, st); break;
+    case 4: launch_filter<4>(f, a, nfs, nreal, st); break;
+    case 5: launch_filter<5>(f, a, nfs, nreal, st); break;
+    case 6: launch_filter<6>(f, a, nfs, nreal, st); break;
+    case 7: launch_filter<7>(f, a, nfs, nreal, st); break;
+    case 8: launch_filter<8>(f, a, nfs, nreal, st); break;
+    default: break;
+    }
+}
+
 int EngineBase::filter_apply(const FilterObj *f, double *Q, int nstate)
 {
     if (!f || !Q) return fail(CMDG_ERR_INVALID, "filter: NULL argument");
-    if (NQ != 5) return fail(CMDG_ERR_UNSUPPORTED, "filter: polynomial order not compiled in");
+    if (NQ < 2 || NQ > 8) return fail(CMDG_ERR_UNSUPPORTED, "filter: polynomial order not compiled in");
     if (nreal <= 0) return CMDG_OK;
     FilterArgs a{};
     a.Q = Q;
@@ -648,7 +672,8 @@ int EngineBase::filter_apply(const FilterObj *f, double *Q, int nstate)
     const bool every = f->direction == DIR_EVERY;
     const bool h = every || f->direction == DIR_HORIZONTAL, v = every || f->direction == DIR_VERTICAL;
     // FilterIndices states are independent: at most CHUNK of them share the LDS of a launch
-    constexpr int CHUNK = 16;
+    // (two LDS buffers of nfs * Np doubles, below the 64 KB a work-group may claim by default)
+    const int CHUNK = std::max(1, std::min(16, (56 * 1024) / (16 * Np)));
     const int ntot = f->target == CMDG_TARGET_INDICES ? f->nindices : ATMOS_NS;
     for (int c0 = 0; c0 < ntot; c0 += CHUNK) {
         const int nfs = std::min(CHUNK, ntot - c0);
@@ -659,15 +684,15 @@ int EngineBase::filter_apply(const FilterObj *f, double *Q, int nstate)
             // one launch per direction, each with its own mass correction (Filters.jl:566-605)
             if (h) {
                 a.do_h = 1, a.do_v = 0;
-                launch_filter<5>(f, a, nfs, nreal, s_comp);
+                launch_filter_nq(NQ, f, a, nfs, nreal, s_comp);
             }
             if (v) {
                 a.do_h = 0, a.do_v = 1;
-                launch_filter<5>(f, a, nfs, nreal, s_comp);
+                launch_filter_nq(NQ, f, a, nfs, nreal, s_comp);
             }
         } else {
             a.do_h = h, a.do_v = v;
-            launch_filter<5>(f, a, nfs, nreal, s_comp);
+            launch_filter_nq(NQ, f, a, nfs, nreal, s_comp);
         }
         prof_end(s_comp);
     }

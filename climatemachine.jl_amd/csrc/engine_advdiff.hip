@@ -36,10 +36,16 @@ EngineBase *make_engine_advdiff(const cmdg_desc *d, std::string &err)
         err = "AdvectionDiffusion: num_equations != 1 is not compiled in";
         return nullptr;
     }
-    switch (d->N[0]) {
+    switch (d->N[0]) {  // NQ = N + 1 is a template parameter of every kernel
+    case 1: return pick<2>(d, err);
+    case 2: return pick<3>(d, err);
+    case 3: return pick<4>(d, err);
     case 4: return pick<5>(d, err);
+    case 5: return pick<6>(d, err);
+    case 6: return pick<7>(d, err);
+    case 7: return pick<8>(d, err);
     default:
-        err = "AdvectionDiffusion: polynomial order not compiled in (have N = 4)";
+        err = "AdvectionDiffusion: polynomial order not compiled in (have N = 1..7)";
         return nullptr;
     }
 }

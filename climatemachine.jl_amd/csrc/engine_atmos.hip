@@ -43,10 +43,13 @@ EngineBase *make_engine_atmos(const cmdg_desc *d, std::string &err)
         err = "DryAtmos: reference state / hyperdiffusion need an orientation";
         return nullptr;
     }
-    switch (d->N[0]) {
+    switch (d->N[0]) {  // element-per-workgroup kernels: LDS bounds the order (N = 6 needs > 64 KB)
+    case 2: return pick<3>(d, err);
+    case 3: return pick<4>(d, err);
     case 4: return pick<5>(d, err);
+    case 5: return pick<6>(d, err);
     default:
-        err = "DryAtmos: polynomial order not compiled in (have N = 4)";
+        err = "DryAtmos: polynomial order not compiled in (have N = 2..5)";
         return nullptr;
     }
 }
