@@ -46,6 +46,24 @@ class CmdgDesc(C.Structure):
     ]
 
 
+MAX_HOOK_OPS = 4
+
+
+class CmdgRhsHooks(C.Structure):
+    """``cmdg_rhs_hooks`` of include/cmdg.h."""
+    _fields_ = [
+        ("npre", C.c_int32), ("pre_filter", C.c_void_p * MAX_HOOK_OPS),
+        ("ncopy", C.c_int32),
+        ("copy_gf_col", C.c_int32 * MAX_HOOK_OPS), ("copy_aux_col", C.c_int32 * MAX_HOOK_OPS),
+        ("copy_scale", C.c_double * MAX_HOOK_OPS),
+        ("has_integral", C.c_int32), ("has_reverse_integral", C.c_int32),
+        ("integral", CmdgStackIntegralDesc), ("reverse_integral", CmdgStackIntegralDesc),
+        ("nsurf", C.c_int32),
+        ("surf_src_col", C.c_int32 * MAX_HOOK_OPS), ("surf_dst_col", C.c_int32 * MAX_HOOK_OPS),
+        ("nvertelem", C.c_int32), ("Imat", C.c_void_p),
+    ]
+
+
 # every symbol include/cmdg.h declares: (name, restype, argtypes)
 _vp, _i32, _i64, _d = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 SYMBOLS = [
@@ -78,6 +96,7 @@ SYMBOLS = [
     ("cmdg_filter_destroy", C.c_int, [_vp, _vp]),
     ("cmdg_filter_apply", C.c_int, [_vp, _vp, _vp, _i32]),
     ("cmdg_set_filters", C.c_int, [_vp, _vp, _vp, _vp]),
+    ("cmdg_set_rhs_hooks", C.c_int, [_vp, _vp]),
     ("cmdg_profile_enable", C.c_int, [_vp, _i32]),
     ("cmdg_profile_get", C.c_int, [_vp, _i32, _vp, _vp]),
     ("cmdg_profile_reset", C.c_int, [_vp]),

@@ -20,6 +20,7 @@ RusanovNumericalFlux, CentralNumericalFluxFirstOrder = 0, 1
 
 PHYSICS_ADVECTION_DIFFUSION = 1
 PHYSICS_DRY_ATMOS = 2
+PHYSICS_HYDROSTATIC_BOUSSINESQ = 3
 
 __all__ = [
     "EveryDirection", "HorizontalDirection", "VerticalDirection",

@@ -329,6 +329,7 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
     if ((r = (x)) != CMDG_OK) return r
     switch (seg) {
     case 0:
+        if (has_hooks) TRY(run_pre_hooks(c));  // update_auxiliary_state!(realelems) of the law
         if (!(grad && fused_update_aux())) launch_update_aux(c, 0, nreal);
         if (comm) TRY(halo_begin(SLOT_Q, c.Qin, ns));
         if (grad) launch_gradients(c, d_interior, ninterior);
@@ -345,6 +346,8 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
             if (ngf > 0) TRY(halo_begin(SLOT_GF, gf, ngf));
             if (hyper) TRY(halo_begin(SLOT_HG, hypgrad, 3 * ngl));
         }
+        // update_auxiliary_state_gradient!(realelems)  (DGModel.jl:210-222)
+        if (has_hooks && ngf > 0) TRY(run_gradient_hooks(c, 0, nreal));
         if (hyper) launch_divgrad(c, d_interior, ninterior);
         break;
     case 2:
@@ -365,7 +368,11 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
     case 4:
         if (comm) {
             if (grad) {
-                if (ngf > 0) TRY(halo_end(SLOT_GF, gf, ngf));
+                if (ngf > 0) {
+                    TRY(halo_end(SLOT_GF, gf, ngf));
+                    // update_auxiliary_state_gradient!(ghostelems)  (DGModel.jl:355-361)
+                    if (has_hooks) TRY(run_gradient_hooks(c, nreal, nelem));
+                }
                 if (hyper) TRY(halo_end(SLOT_HG, hypgrad, 3 * ngl));
             } else {
                 TRY(halo_end(SLOT_Q, c.Qin, ns));
@@ -500,7 +507,7 @@ static void launch_stack(bool reverse, const StackArgs &a, hipStream_t st)
 
 int EngineBase::stack_integral(bool reverse, const double *Q, int nstate, double *aux_arr,
                                int naux_arr, int nvert, const double *Imat_host,
-                               const cmdg_stack_integral_desc *d)
+                               const cmdg_stack_integral_desc *d, int64_t h0, int64_t nh)
 {
     if (NQ < 2 || NQ > 8) return fail(CMDG_ERR_UNSUPPORTED, "stack integral: polynomial order not compiled in");
     if (!stacked) return fail(CMDG_ERR_INVALID, "stack integral: the topology is not stacked");
@@ -516,13 +523,14 @@ int EngineBase::stack_integral(bool reverse, const double *Q, int nstate, double
         if (src < 0 || src >= (st ? nstate : naux_arr) || dst < 0 || dst >= naux_arr)
             return fail(CMDG_ERR_INVALID, "stack integral: column out of range");
     }
-    if (nreal == 0) return CMDG_OK;
-    if (!reverse) {
-        if (!Imat_host) return fail(CMDG_ERR_INVALID, "stack integral: Imat is NULL");
+    if (nh < 0) nh = nreal / nvert;
+    if (nh == 0) return CMDG_OK;
+    if (!reverse && Imat_host) {  // (NULL: the matrix uploaded by an earlier call / the hooks)
         if (!d_Imat) HIPCHK(hipMalloc(&d_Imat, sizeof(double) * NQ * NQ));
         HIPCHK(hipMemcpyAsync(d_Imat, Imat_host, sizeof(double) * NQ * NQ, hipMemcpyHostToDevice, s_comp));
         HIPCHK(hipStreamSynchronize(s_comp));  // Imat_host may be a temporary of the caller
     }
+    if (!reverse && !d_Imat) return fail(CMDG_ERR_INVALID, "stack integral: Imat is NULL");
     StackArgs a{};
     a.Q = Q;
     a.aux = aux_arr;
@@ -533,7 +541,8 @@ int EngineBase::stack_integral(bool reverse, const double *Q, int nstate, double
     a.nvgeo = g.nvgeo;
     a.nvert = nvert;
     a.jcv = 15;  // _JcV (Grids.jl:76-92)
-    a.nhorz = nreal / nvert;
+    a.h0 = h0;
+    a.nhorz = nh;
     // integrals of different variables are independent: four ride in one launch
     for (int c0 = 0; c0 < d->nout; c0 += 4) {
         const int n = std::min(4, d->nout - c0);
@@ -563,6 +572,73 @@ int EngineBase::stack_integral(bool reverse, const double *Q, int nstate, double
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CMDG_ERR_HIP, std::string("stack integral launch: ") + hipGetErrorString(e));
+    return CMDG_OK;
+}
+
+// ---- law-specific update_auxiliary_state! / update_auxiliary_state_gradient! as hooks ----
+int EngineBase::set_hooks(const cmdg_rhs_hooks *hk)
+{
+    if (!hk) {
+        has_hooks = false;
+        return CMDG_OK;
+    }
+    if (hk->npre < 0 || hk->npre > CMDG_MAX_HOOK_OPS || hk->ncopy < 0 || hk->ncopy > CMDG_MAX_HOOK_OPS ||
+        hk->nsurf < 0 || hk->nsurf > CMDG_MAX_HOOK_OPS)
+        return fail(CMDG_ERR_INVALID, "hooks: too many operations");
+    const bool cols = hk->has_integral || hk->has_reverse_integral || hk->nsurf > 0;
+    if (cols && (!stacked || hk->nvertelem < 1 || nreal % hk->nvertelem || nghost % hk->nvertelem))
+        return fail(CMDG_ERR_INVALID, "hooks: column operators need a stacked topology and nvertelem");
+    for (int i = 0; i < hk->ncopy; ++i)
+        if (hk->copy_gf_col[i] < 0 || hk->copy_gf_col[i] >= ngf || hk->copy_aux_col[i] < 0 ||
+            hk->copy_aux_col[i] >= naux)
+            return fail(CMDG_ERR_INVALID, "hooks: copy column out of range");
+    for (int i = 0; i < hk->nsurf; ++i)
+        if (hk->surf_src_col[i] < 0 || hk->surf_src_col[i] >= naux || hk->surf_dst_col[i] < 0 ||
+            hk->surf_dst_col[i] >= naux)
+            return fail(CMDG_ERR_INVALID, "hooks: surface column out of range");
+    for (int i = 0; i < hk->npre; ++i)
+        if (!hk->pre_filter[i]) return fail(CMDG_ERR_INVALID, "hooks: NULL filter");
+    if (hk->has_integral) {
+        if (!hk->Imat) return fail(CMDG_ERR_INVALID, "hooks: Imat is NULL");
+        if (!d_Imat) HIPCHK(hipMalloc(&d_Imat, sizeof(double) * NQ * NQ));
+        HIPCHK(hipMemcpy(d_Imat, hk->Imat, sizeof(double) * NQ * NQ, hipMemcpyHostToDevice));
+    }
+    hooks = *hk;
+    hooks.Imat = nullptr;
+    has_hooks = true;
+    return CMDG_OK;
+}
+
+int EngineBase::run_pre_hooks(const RhsCtx &c)
+{
+    for (int i = 0; i < hooks.npre; ++i)
+        if (int r = filter_apply(reinterpret_cast<const FilterObj *>(hooks.pre_filter[i]), c.Qin, ns))
+            return r;
+    return CMDG_OK;
+}
+
+int EngineBase::run_gradient_hooks(const RhsCtx &c, int64_t e0, int64_t e1)
+{
+    if (e1 <= e0) return CMDG_OK;
+    const int64_t n = (e1 - e0) * Np;
+    const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 65535);
+    for (int i = 0; i < hooks.ncopy; ++i)
+        hipLaunchKernelGGL(k_scaled_column_copy, dim3(nb), dim3(256), 0, s_comp, aux, naux,
+                           hooks.copy_aux_col[i], gf, ngf, hooks.copy_gf_col[i], hooks.copy_scale[i],
+                           Np, e0, e1);
+    const int nv = hooks.nvertelem;
+    if (hooks.has_integral)
+        if (int r = stack_integral(false, c.Qin, ns, aux, naux, nv, nullptr, &hooks.integral, e0 / nv,
+                                   (e1 - e0) / nv))
+            return r;
+    if (hooks.has_reverse_integral)
+        if (int r = stack_integral(true, nullptr, 0, aux, naux, nv, nullptr, &hooks.reverse_integral,
+                                   e0 / nv, (e1 - e0) / nv))
+            return r;
+    for (int i = 0; i < hooks.nsurf; ++i)
+        hipLaunchKernelGGL(k_surface_to_column, dim3(nb), dim3(256), 0, s_comp, aux, naux,
+                           hooks.surf_src_col[i], hooks.surf_dst_col[i], NQ * NQ, NQ, nv, e0 / nv,
+                           (e1 - e0) / nv);
     return CMDG_OK;
 }
 
@@ -758,6 +834,7 @@ int cmdg_physics_counts(int32_t physics_id, const int32_t *iparam, int32_t out[6
     switch (physics_id) {
     case CMDG_PHYSICS_ADVECTION_DIFFUSION: return counts_advdiff(iparam, out);
     case CMDG_PHYSICS_DRY_ATMOS: return counts_atmos(iparam, out);
+    case CMDG_PHYSICS_HYDROSTATIC_BOUSSINESQ: return counts_ocean(iparam, out);
     default: return CMDG_ERR_UNSUPPORTED;
     }
 }
@@ -780,6 +857,7 @@ int cmdg_create(const cmdg_desc *d, cmdg_handle *out)
     switch (d->physics_id) {
     case CMDG_PHYSICS_ADVECTION_DIFFUSION: e = make_engine_advdiff(d, err); break;
     case CMDG_PHYSICS_DRY_ATMOS: e = make_engine_atmos(d, err); break;
+    case CMDG_PHYSICS_HYDROSTATIC_BOUSSINESQ: e = make_engine_ocean(d, err); break;
     default: err = "unknown physics_id"; break;
     }
     if (!e) {
@@ -1073,6 +1151,12 @@ int cmdg_set_filters(cmdg_handle h, cmdg_filter gradient_filter, cmdg_filter ten
     e->tendency_filter = tfl;
     e->step_filter = reinterpret_cast<FilterObj *>(step_filter);
     return CMDG_OK;
+}
+
+int cmdg_set_rhs_hooks(cmdg_handle h, const cmdg_rhs_hooks *hooks)
+{
+    if (!h) return CMDG_ERR_INVALID;
+    return set_err(h, h->eng->set_hooks(hooks));
 }
 
 int cmdg_profile_enable(cmdg_handle h, int32_t on)

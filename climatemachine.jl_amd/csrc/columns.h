@@ -20,7 +20,7 @@ struct StackArgs {
     const double *vgeo;
     const double *Imat;  // device (NQ, NQ) column-major
     int nstate, naux, nvgeo, nvert, jcv;
-    int64_t nhorz;
+    int64_t h0, nhorz;  // horizontal elements [h0, h0 + nhorz)
     int is_state[STACK_MAXOUT], src[STACK_MAXOUT], dst[STACK_MAXOUT];
     double scale[STACK_MAXOUT];
 };
@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void k_stack_integral(StackArgs a)
     if (tid < NQ * NQ) sI[tid] = a.Imat[tid];
     __syncthreads();
     const int sl = tid / Nij, ij = tid % Nij;
-    const int64_t eh = (int64_t)blockIdx.x * SPB + sl;
-    if (sl >= SPB || eh >= a.nhorz) return;
+    const int64_t eh = a.h0 + (int64_t)blockIdx.x * SPB + sl;
+    if (sl >= SPB || eh >= a.h0 + a.nhorz) return;
     double lint[NOUT][NQ], lker[NOUT][NQ];
 #pragma unroll
     for (int s = 0; s < NOUT; ++s)
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void k_reverse_stack_integral(StackArgs a)
     constexpr int Nij = NQ * NQ, Np = Nij * NQ, SPB = 256 / Nij;
     const int tid = threadIdx.x;
     const int sl = tid / Nij, ij = tid % Nij;
-    const int64_t eh = (int64_t)blockIdx.x * SPB + sl;
-    if (sl >= SPB || eh >= a.nhorz) return;
+    const int64_t eh = a.h0 + (int64_t)blockIdx.x * SPB + sl;
+    if (sl >= SPB || eh >= a.h0 + a.nhorz) return;
     double lT[NOUT];
     {
         const int ijk = ij + Nij * (NQ - 1);
@@ -101,6 +101,41 @@ __global__ __launch_bounds__(256) void k_reverse_stack_integral(StackArgs a)
                 a.aux[ijk + (int64_t)Np * (a.dst[s] + (int64_t)a.naux * e)] = lT[s] - v;
             }
         }
+    }
+}
+
+// aux[:, dst, e] = scale * src[:, scol, e] for elements [e0, e1)
+static __global__ void k_scaled_column_copy(double *__restrict__ aux, int naux, int dst,
+                                            const double *__restrict__ src, int nsrc, int scol,
+                                            double scale, int Np, int64_t e0, int64_t e1)
+{
+    const int64_t n = (e1 - e0) * Np;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = e0 + i / Np;
+        const int ijk = (int)(i % Np);
+        aux[ijk + (int64_t)Np * (dst + (int64_t)naux * e)] =
+            scale * src[ijk + (int64_t)Np * (scol + (int64_t)nsrc * e)];
+    }
+}
+
+// aux[(i,j,k), dst, every element of the stack] = aux[(i,j,top k), src, top element]
+// (the `boxy_wz0 .= flat_wz0` broadcast of hydrostatic_boussinesq_model.jl:717-723)
+static __global__ void k_surface_to_column(double *__restrict__ aux, int naux, int src, int dst,
+                                           int Nij, int Nqk, int nvert, int64_t h0, int64_t nhorz)
+{
+    const int Np = Nij * Nqk;
+    const int64_t n = nhorz * nvert * Np;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int ijk = (int)(i % Np);
+        const int64_t ecol = i / Np;  // element counted from h0 * nvert
+        const int64_t eh = h0 + ecol / nvert;
+        const int64_t e = h0 * nvert + ecol;
+        const int64_t et = (nvert - 1) + eh * nvert;
+        const int ij = ijk % Nij;
+        aux[ijk + (int64_t)Np * (dst + (int64_t)naux * e)] =
+            aux[ij + Nij * (Nqk - 1) + (int64_t)Np * (src + (int64_t)naux * et)];
     }
 }
 

@@ -123,7 +123,13 @@ struct EngineBase {
     int courant(int mode, int kind, const double *Q, double dt, double t, int dir, double *out);
     double *d_elemred = nullptr;  // (nreal) per-element extrema
     int stack_integral(bool reverse, const double *Q, int nstate, double *aux_arr, int naux_arr,
-                       int nvert, const double *Imat_host, const cmdg_stack_integral_desc *d);
+                       int nvert, const double *Imat_host, const cmdg_stack_integral_desc *d,
+                       int64_t h0 = 0, int64_t nh = -1);
+    bool has_hooks = false;
+    cmdg_rhs_hooks hooks{};
+    int set_hooks(const cmdg_rhs_hooks *hk);
+    int run_pre_hooks(const RhsCtx &c);
+    int run_gradient_hooks(const RhsCtx &c, int64_t e0, int64_t e1);
     double *d_Imat = nullptr;
     int filter_create(const cmdg_filter_desc *d, FilterObj **out);
     int filter_apply(const FilterObj *f, double *Q, int nstate);
@@ -278,5 +284,7 @@ EngineBase *make_engine_advdiff(const cmdg_desc *d, std::string &err);
 int counts_advdiff(const int32_t *iparam, int32_t out[6]);
 EngineBase *make_engine_atmos(const cmdg_desc *d, std::string &err);
 int counts_atmos(const int32_t *iparam, int32_t out[6]);
+EngineBase *make_engine_ocean(const cmdg_desc *d, std::string &err);
+int counts_ocean(const int32_t *iparam, int32_t out[6]);
 
 }  // namespace cmdg

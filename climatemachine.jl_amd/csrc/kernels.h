@@ -138,12 +138,15 @@ __device__ __forceinline__ void nf_first_order(const typename P::Params &prm, in
         Vec<NS> wM, wP;
         P::wavespeed(prm, wM, n, QM, auxM, t, facedir);
         P::wavespeed(prm, wP, n, QP, auxP, t, facedir);
+        Vec<NS> pen;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const double mw = wM[s] > wP[s] ? wM[s] : wP[s];
-            const double pen = mw * (QM[s] - QP[s]);
-            fluxn[s] += pen / 2;
+            pen[s] = mw * (QM[s] - QP[s]);
         }
+        if constexpr (P::HAS_PENALTY) P::update_penalty(prm, pen, n, QM, QP);  // (:266-279)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fluxn[s] += pen[s] / 2;
     }
 }
 

@@ -238,6 +238,11 @@ struct AdvDiff {
     __device__ static void update_aux(const Params &, const double *, double *, double) {}
     // the test law defines no local_courant function
     static constexpr bool HAS_COURANT = false;
+    static constexpr bool HAS_PENALTY = false;  // update_penalty! is the default no-op
+    __device__ static void update_penalty(const Params &, double *, const double *, const double *,
+                                          const double *)
+    {
+    }
     __device__ static double courant(const Params &, int, const double *, const double *,
                                      const double *, double, double, double, int)
     {

@@ -112,6 +112,11 @@ struct DryAtmos {
 
     // ---- local Courant numbers: src/Atmos/Model/courant.jl:12-83 ------------------------
     static constexpr bool HAS_COURANT = true;
+    static constexpr bool HAS_PENALTY = false;  // update_penalty! is the default no-op
+    __device__ static void update_penalty(const Params &, double *, const double *, const double *,
+                                          const double *)
+    {
+    }
     __device__ static double courant(const Params &m, int kind, const double *Q, const double *aux,
                                      const double *gf, double dx, double dt, double, int direction)
     {

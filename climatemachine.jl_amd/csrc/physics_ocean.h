@@ -1,0 +1,221 @@
+// Device functor for the hydrostatic Boussinesq ocean model (uncoupled), restating
+//   src/Ocean/HydrostaticBoussinesq/hydrostatic_boussinesq_model.jl:107-144 (state, aux),
+//       :175-290 (gradient argument / flux), :419-520 (first-order fluxes), :539-552
+//       (second-order flux), :571-606 (source), :613 (wavespeed), :621-635 (update_penalty!)
+//   src/Ocean/HydrostaticBoussinesq/bc_velocity.jl, bc_temperature.jl (OceanBC)
+//   src/Ocean/OceanProblems/simple_box_problem.jl:56-127 (Coriolis parameter)
+// The law's update_auxiliary_state! (filters) and update_auxiliary_state_gradient! (column
+// integrals) are operator hooks (cmdg_set_rhs_hooks), not part of this functor.
+//
+// Parameter block: iparam[0] momentum advection, [1] tracer advection, [2] Coriolis (0 fixed
+// box f = -0, 1 rotating f = f_o, 2 beta plane), [6] nbc, [7..13] bc = velocity kind + 8 *
+// temperature kind (velocity 1 Impenetrable(NoSlip), 2 Impenetrable(FreeSlip), 3
+// Penetrable(FreeSlip); temperature 0 Insulating); dparam[0..10] = grav c_h c_z alpha_T nu_h
+// nu_z kappa_h kappa_z kappa_c f_o beta.
+#pragma once
+#include "cmdg_common.h"
+
+namespace cmdg {
+
+struct OceanParams {
+    int madv, tadv, cor, nbc;
+    int bc[8];
+    double grav, ch, cz, aT, nuh, nuz, kh, kz, kc, fo, beta;
+};
+
+struct HydroBoussinesq {
+    using Params = OceanParams;
+    enum { U = 0, V = 1, ETA = 2, TH = 3 };
+    enum { AY = 0, AW = 1, APKIN = 2, AWZ0 = 3 };
+    enum { GDIVH = 0, GNU = 1, GKAPPA = 7 };
+    static constexpr int NS = 4, NAUX = 8, NGRAD = 5, NGF = 10, NGL = 0, NHYP = 0;
+    static constexpr bool HAS_UPDATE_AUX = false, FUSE_UPDATE_AUX = false, HAS_SOURCE = true;
+    static constexpr bool HAS_COURANT = false, HAS_PENALTY = true;
+    static constexpr int NUPD = 0, NDER = 0;
+    __host__ __device__ static constexpr int upd_aux(int) { return 0; }
+    __host__ __device__ static constexpr int hv_indexmap(int) { return 0; }
+    __host__ __device__ static bool needs_gradflux(const Params &) { return true; }
+    // the face fluxes read w and pkin (and y never): aux columns 1, 2
+    static constexpr int NFAUX = 2;
+    __host__ __device__ static constexpr int face_aux(int i) { return 1 + i; }
+
+    static void make_params(Params &p, const int32_t *ip, const double *dp)
+    {
+        p.madv = ip[0];
+        p.tadv = ip[1];
+        p.cor = ip[2];
+        p.nbc = ip[6];
+        for (int i = 0; i < 7; ++i) p.bc[i] = ip[7 + i];
+        p.bc[7] = 0;
+        p.grav = dp[0];
+        p.ch = dp[1];
+        p.cz = dp[2];
+        p.aT = dp[3];
+        p.nuh = dp[4];
+        p.nuz = dp[5];
+        p.kh = dp[6];
+        p.kz = dp[7];
+        p.kc = dp[8];
+        p.fo = dp[9];
+        p.beta = dp[10];
+    }
+
+    __device__ static void flux_first_order(const Params &m, double *F, const double *Q,
+                                            const double *aux, double, int)
+    {
+        const double ge = m.grav * Q[ETA], gp = m.grav * aux[APKIN];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double I = d == c ? 1.0 : -0.0;  // I^h (3 x 2)
+                F[d + 3 * c] += ge * I;
+                F[d + 3 * c] += gp * I;
+            }
+        const double v[3] = {Q[U], Q[V], aux[AW]};
+        if (m.madv) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) F[d + 3 * c] += v[d] * Q[c];
+        }
+        if (m.tadv) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) F[d + 3 * TH] += v[d] * Q[TH];
+        }
+    }
+    __device__ static void flux_second_order(const Params &, double *F, const double *,
+                                             const double *gf, const double *, const double *,
+                                             double)
+    {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) F[q] += gf[GNU + q];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) F[d + 3 * TH] += gf[GKAPPA + d];
+    }
+    __device__ static double coriolis(const Params &m, double y)
+    {
+        return m.cor == 0 ? -0.0 : (m.cor == 1 ? m.fo : m.fo + m.beta * y);
+    }
+    __device__ static void source(const Params &m, double *S, const double *Q, const double *,
+                                  const double *aux, const double *, double, int)
+    {
+        S[ETA] += aux[AWZ0];
+        const double f = coriolis(m, aux[AY]);
+        S[U] -= -f * Q[V];
+        S[V] -= f * Q[U];
+        S[U] += 0;  // forcing: noforcing(args...) = 0
+        S[V] += 0;
+        S[ETA] += 0;
+        S[TH] += 0;
+    }
+    __device__ static void init_derived(const Params &, double *, const double *) {}
+    __device__ static void gradient_argument(const Params &, double *G, const double *Q,
+                                             const double *, double)
+    {
+        G[4] = Q[TH];
+        G[0] = Q[U];
+        G[1] = Q[V];
+    }
+    __device__ static void gradient_flux(const Params &m, double *D, const double *g,
+                                         const double *, const double *, double)
+    {
+        D[GDIVH] = g[0 + 3 * 0] + g[1 + 3 * 1];
+        const double nu[3] = {m.nuh, m.nuh, m.nuz};
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) D[GNU + d + 3 * c] = -nu[d] * g[d + 3 * c];
+        const double kap[3] = {m.kh, m.kh, g[2 + 3 * 4] < 0 ? m.kc : m.kz};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) D[GKAPPA + d] = -kap[d] * g[d + 3 * 4];
+    }
+    __device__ static void post_gradient_laplacian(const Params &, double *, const double *,
+                                                   const double *, const double *, double)
+    {
+    }
+    __device__ static void wavespeed(const Params &m, double *ws, const double *n, const double *,
+                                     const double *, double, int)
+    {
+        const double w = fabs(m.ch * n[0] + m.ch * n[1] + m.cz * n[2]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) ws[s] = w;
+    }
+    // update_penalty!(::RusanovNumericalFlux, ::HBModel, ...): no penalty on eta
+    __device__ static void update_penalty(const Params &, double *pen, const double *,
+                                          const double *, const double *)
+    {
+        pen[ETA] = -0.0;
+    }
+    __device__ static void boundary_state(const Params &m, int kind, int bctag, double *QP,
+                                          double *auxP, const double *n, const double *QM,
+                                          const double *auxM, double, const double *,
+                                          const double *)
+    {
+        const int bv = m.bc[bctag - 1] & 7;
+        if (bv == 1) {  // Impenetrable(NoSlip)
+            if (kind == BS_FIRST) {
+                QP[U] = -QM[U];
+                QP[V] = -QM[V];
+                auxP[AW] = -auxM[AW];
+            } else {
+                QP[U] = -0.0;
+                QP[V] = -0.0;
+                auxP[AW] = -0.0;
+            }
+        } else if (bv == 2) {  // Impenetrable(FreeSlip)
+            const double v[3] = {QM[U], QM[V], auxM[AW]};
+            const double dn = kind == BS_FIRST
+                                  ? (2 * n[0]) * v[0] + (2 * n[1]) * v[1] + (2 * n[2]) * v[2]
+                                  : n[0] * v[0] + n[1] * v[1] + n[2] * v[2];
+            QP[U] = v[0] - dn * n[0];
+            QP[V] = v[1] - dn * n[1];
+            auxP[AW] = v[2] - dn * n[2];
+        }
+        QP[TH] = QM[TH];  // Insulating
+    }
+    __device__ static void boundary_flux_second_order(
+        const Params &m, int bctag, double *F, double *QP, double *gfP, double *hypP, double *auxP,
+        const double *n, const double *QM, const double *gfM, const double *, const double *auxM,
+        double t, const double *, const double *, const double *)
+    {
+        const int bv = m.bc[bctag - 1] & 7;
+        if (bv == 1) {
+            QP[U] = -QM[U];
+            QP[V] = -QM[V];
+            auxP[AW] = -auxM[AW];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) gfP[GNU + q] = gfM[GNU + q];
+        } else {
+            QP[U] = QM[U];
+            QP[V] = QM[V];
+            auxP[AW] = auxM[AW];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) gfP[GNU + d + 3 * c] = n[d] * -0.0;
+        }
+        QP[TH] = QM[TH];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gfP[GKAPPA + d] = n[d] * -0.0;
+        flux_second_order(m, F, QP, gfP, hypP, auxP, t);
+    }
+    __device__ static void boundary_state_divergence(const Params &, int, double *, double *,
+                                                     const double *, const double *,
+                                                     const double *, double)
+    {
+    }
+    __device__ static void boundary_state_higher_order(const Params &, int, double *, double *,
+                                                       double *, const double *, const double *,
+                                                       const double *, const double *, double)
+    {
+    }
+    __device__ static void update_aux(const Params &, const double *, double *, double) {}
+    __device__ static double courant(const Params &, int, const double *, const double *,
+                                     const double *, double, double, double, int)
+    {
+        return 0.0;
+    }
+};
+
+}  // namespace cmdg

@@ -224,6 +224,46 @@ class DGModel:
             self.handle, aux.data_ptr(), aux.shape[1], int(self.grid.topology.stacksize),
             C.byref(d)), self.handle)
 
+    def set_rhs_hooks(self, pre_filters=(), gradflux_to_aux=(), integral=None,
+                      reverse_integral=None, surface_to_column=()):
+        """The composition a law's ``update_auxiliary_state!`` /
+        ``update_auxiliary_state_gradient!`` overrides stand for (see ``cmdg_rhs_hooks`` in
+        include/cmdg.h); ``set_rhs_hooks()`` with no arguments clears them."""
+        if not (pre_filters or gradflux_to_aux or integral or reverse_integral or surface_to_column):
+            self._hooks = None
+            _lib.check(self.L.cmdg_set_rhs_hooks(self.handle, None), self.handle)
+            return
+        hk = _lib.CmdgRhsHooks()
+        hk.npre = len(pre_filters)
+        for i, f in enumerate(pre_filters):
+            hk.pre_filter[i] = f.handle
+        hk.ncopy = len(gradflux_to_aux)
+        for i, (g, a, sc) in enumerate(gradflux_to_aux):
+            hk.copy_gf_col[i], hk.copy_aux_col[i], hk.copy_scale[i] = int(g), int(a), float(sc)
+        if integral:
+            n = len(integral["dst"])
+            hk.has_integral = 1
+            hk.integral.nout = n
+            for s in range(n):
+                hk.integral.src_is_state[s], hk.integral.src_col[s] = integral["src"][s]
+                hk.integral.scale[s] = float(integral.get("scale", [1.0] * n)[s])
+                hk.integral.dst_col[s] = int(integral["dst"][s])
+        if reverse_integral:
+            n = len(reverse_integral["rdst"])
+            hk.has_reverse_integral = 1
+            hk.reverse_integral.nout = n
+            for s in range(n):
+                hk.reverse_integral.rsrc_col[s] = int(reverse_integral["rsrc"][s])
+                hk.reverse_integral.rdst_col[s] = int(reverse_integral["rdst"][s])
+        hk.nsurf = len(surface_to_column)
+        for i, (a, b) in enumerate(surface_to_column):
+            hk.surf_src_col[i], hk.surf_dst_col[i] = int(a), int(b)
+        hk.nvertelem = int(self.grid.topology.stacksize or 0)
+        Imat = np.ascontiguousarray(np.asarray(self.grid.Imat[-1], dtype=np.float64).T)
+        hk.Imat = Imat.ctypes.data
+        self._hooks = (hk, Imat, list(pre_filters))      # keep alive
+        _lib.check(self.L.cmdg_set_rhs_hooks(self.handle, C.byref(hk)), self.handle)
+
     def set_filters(self, gradient_filter=None, tendency_filter=None, step_filter=None):
         """``DGModel(...; gradient_filter, tendency_filter)`` (DGModel.jl:44-45, applied at
         :185-193 and :417-425) and the every-step user filter callback of

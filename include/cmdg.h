@@ -40,7 +40,10 @@ enum { CMDG_EVERY_DIRECTION = 0, CMDG_HORIZONTAL_DIRECTION = 1, CMDG_VERTICAL_DI
  * fluxes are the central ones (:668, :65), as in every configuration in scope */
 enum { CMDG_RUSANOV = 0, CMDG_CENTRAL_FIRST_ORDER = 1 };
 /* balance laws carried as device functors (pointwise Julia physics cannot cross a C ABI) */
-enum { CMDG_PHYSICS_ADVECTION_DIFFUSION = 1, CMDG_PHYSICS_DRY_ATMOS = 2 };
+enum {
+    CMDG_PHYSICS_ADVECTION_DIFFUSION = 1, CMDG_PHYSICS_DRY_ATMOS = 2,
+    CMDG_PHYSICS_HYDROSTATIC_BOUSSINESQ = 3
+};
 
 /* Construction record: the fields of `DGModel(balance_law, grid, nf1, nf2, nfgrad;
  * state_auxiliary, state_gradient_flux, states_higher_order, direction,
@@ -233,6 +236,38 @@ int cmdg_filter_apply(cmdg_handle h, cmdg_filter f, double *Q, int32_t nstate);
  * NULL clears a slot.  The filters must outlive their use. */
 int cmdg_set_filters(cmdg_handle h, cmdg_filter gradient_filter, cmdg_filter tendency_filter,
                      cmdg_filter step_filter);
+
+/* ---- law-specific update_auxiliary_state! / update_auxiliary_state_gradient! ----------- */
+/* Laws whose auxiliary state needs more than a nodal refresh override these two methods in
+ * the reference (BalanceLaws/interface.jl:276-305; called at DGModel.jl:110-116,161-172 and
+ * :210-222,355-361).  Their bodies are compositions of operators this library has; the hooks
+ * record such a composition and the operator runs it at the reference's call sites:
+ *   before the gradient pass (real elements): pre_filter[i] applied to Q
+ *       -- HBModel: vertical cutoff filter on u, exponential filter on theta
+ *          (hydrostatic_boussinesq_model.jl:654-680)
+ *   after the gradient pass (real elements, and ghost elements once their gradient flux
+ *   arrived):  aux[:, copy_aux_col[i]] = copy_scale[i] * gradflux[:, copy_gf_col[i]];
+ *       upward column integral; downward column integral; aux[:, surf_dst_col[i]] over each
+ *       stack = aux[:, surf_src_col[i]] at the top node of the stack
+ *       -- HBModel: w = -div_h u, (w, pkin) integrals, wz0 (:693-726) */
+#define CMDG_MAX_HOOK_OPS 4
+typedef struct cmdg_rhs_hooks {
+    int32_t npre;
+    cmdg_filter pre_filter[CMDG_MAX_HOOK_OPS];
+    int32_t ncopy;
+    int32_t copy_gf_col[CMDG_MAX_HOOK_OPS], copy_aux_col[CMDG_MAX_HOOK_OPS];
+    double copy_scale[CMDG_MAX_HOOK_OPS];
+    int32_t has_integral, has_reverse_integral;
+    cmdg_stack_integral_desc integral;         /* src/scale/dst: upward integral */
+    cmdg_stack_integral_desc reverse_integral; /* rsrc/rdst: downward integral; both act on
+                                                  the handle's state_auxiliary */
+    int32_t nsurf;
+    int32_t surf_src_col[CMDG_MAX_HOOK_OPS], surf_dst_col[CMDG_MAX_HOOK_OPS];
+    int32_t nvertelem;
+    const double *Imat; /* HOST (Nq, Nq) column-major grid.Imat[dim] */
+} cmdg_rhs_hooks;
+/* hooks == NULL clears them.  Filters must outlive their use. */
+int cmdg_set_rhs_hooks(cmdg_handle h, const cmdg_rhs_hooks *hooks);
 
 /* ---- measurement --------------------------------------------------------------- */
 enum {

@@ -233,11 +233,13 @@ static void nf_first_order(const orc_physics *ph, double *fluxn, const double *n
         double wM[ORC_MAXS], wP[ORC_MAXS];
         ph->wavespeed(ph->p, wM, n, QM, auxM, t, facedir);
         ph->wavespeed(ph->p, wP, n, QP, auxP, t, facedir);
+        double pen[ORC_MAXS];
         for (int s = 0; s < ns; ++s) {
             const double mw = wM[s] > wP[s] ? wM[s] : wP[s];
-            const double pen = mw * (QM[s] - QP[s]);
-            fluxn[s] += pen / 2;
+            pen[s] = mw * (QM[s] - QP[s]);
         }
+        if (ph->update_penalty) ph->update_penalty(ph->p, pen, n, QM, QP);
+        for (int s = 0; s < ns; ++s) fluxn[s] += pen[s] / 2;
     }
 }
 

@@ -67,6 +67,10 @@ typedef struct orc_physics {
      * 1 nondiffusive, 2 diffusive; NULL when the law defines none */
     double (*courant)(const void *p, int kind, const double *Q, const double *aux,
                       const double *gf, double dx, double dt, double t, int direction);
+    /* update_penalty!(::RusanovNumericalFlux, law, n, lambda, penalty, Q-, A-, Q+, A+, t)
+     * (NumericalFluxes.jl:222, 266-279); NULL = the default no-op */
+    void (*update_penalty)(const void *p, double *penalty, const double *n, const double *QM,
+                           const double *QP);
 } orc_physics;
 
 typedef struct orc_grid {

@@ -45,7 +45,8 @@ class _Physics(C.Structure):
                     "flux_first_order", "flux_second_order", "source", "gradient_argument",
                     "gradient_flux", "post_gradient_laplacian", "wavespeed", "boundary_state",
                     "boundary_flux_second_order", "boundary_state_divergence",
-                    "boundary_state_higher_order", "update_aux", "courant")])
+                    "boundary_state_higher_order", "update_aux", "courant",
+                    "update_penalty")])
 
 
 class _Grid(C.Structure):
@@ -62,6 +63,9 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.orc_advdiff_new.restype = C.POINTER(_Physics)
         _LIB.orc_advdiff_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        if hasattr(_LIB, "orc_ocean_new"):
+            _LIB.orc_ocean_new.restype = C.POINTER(_Physics)
+            _LIB.orc_ocean_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         if hasattr(_LIB, "orc_atmos_new"):
             _LIB.orc_atmos_new.restype = C.POINTER(_Physics)
             _LIB.orc_atmos_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -115,7 +119,7 @@ class OraclePhysics:
         ip, dp = law.descriptor()
         self._ip = np.ascontiguousarray(ip, dtype=np.int32)
         self._dp = np.ascontiguousarray(dp, dtype=np.float64)
-        ctor = {1: "orc_advdiff_new", 2: "orc_atmos_new"}[law.physics_id]
+        ctor = {1: "orc_advdiff_new", 2: "orc_atmos_new", 3: "orc_ocean_new"}[law.physics_id]
         self.c = getattr(lib(), ctor)(_p(self._ip), _p(self._dp), int(nf_first))
         ph = self.c.contents
         self.ns, self.naux, self.ngrad = ph.ns, ph.naux, ph.ngrad
@@ -163,6 +167,10 @@ class OracleDGModel:
         # (filter, target) pairs: DGModel(...; gradient_filter, tendency_filter) DGModel.jl:44-45
         self.gradient_filter = None
         self.tendency_filter = None
+        # law-specific update_auxiliary_state! / update_auxiliary_state_gradient! methods
+        # (callables (dg, Q, t, "real" | "ghost")); None = the nodal default / `false`
+        self.update_auxiliary_state_hook = None
+        self.update_auxiliary_state_gradient_hook = None
 
     # -- launchers (SpaceDiscretization.jl) ----------------------------------
     def _dirs(self, d):
@@ -261,6 +269,9 @@ class OracleDGModel:
                     C.c_double(alpha))
 
     def update_auxiliary_state(self, Q, t, which):
+        if self.update_auxiliary_state_hook is not None:     # a law-specific method
+            self.update_auxiliary_state_hook(self, Q, t, which)
+            return
         g = self.grid
         e0, e1 = (0, g.nreal) if which == "real" else (g.nreal, g.nelem)
         self.L.orc_update_auxiliary_state(self.ph.c, C.byref(self.og.c), _p(Q),
@@ -291,6 +302,8 @@ class OracleDGModel:
                     tok_gf = ex.begin(self.state_gradient_flux, ph.ngf)
                 if ph.nhyp > 0:
                     tok_hg = ex.begin(self.Qhypervisc_grad, 3 * ph.ngl)
+            if ph.ngf > 0 and self.update_auxiliary_state_gradient_hook is not None:
+                self.update_auxiliary_state_gradient_hook(self, Q, t, "real")   # DGModel.jl:210-222
         if ph.nhyp > 0:
             self.launch_volume_divergence_of_gradients()
             self.launch_interface_divergence_of_gradients(t, "interior")
@@ -312,6 +325,8 @@ class OracleDGModel:
             if ph.ngf > 0 or ph.nhyp > 0:
                 if ph.ngf > 0:
                     ex.end(self.state_gradient_flux, ph.ngf, tok_gf)
+                    if self.update_auxiliary_state_gradient_hook is not None:   # DGModel.jl:355-361
+                        self.update_auxiliary_state_gradient_hook(self, Q, t, "ghost")
                 if ph.nhyp > 0:
                     ex.end(self.Qhypervisc_grad, 3 * ph.ngl, tok_hg)
             else:
@@ -457,6 +472,56 @@ def reverse_indefinite_stack_integral(law, og, Q, aux, horzelems=None):
     Qp = _p(Q) if Q is not None and Q.size else None
     lib().orc_reverse_indefinite_stack_integral(law, C.byref(og.c), int(nv), Qp, _p(aux),
                                                 C.c_int64(h0), C.c_int64(h1))
+
+
+# ---- HydrostaticBoussinesqModel: update_auxiliary_state! / ..._gradient! ------------------
+def hydrostatic_boussinesq_hooks(dg, vert_filter, exp_filter):
+    """Installs on ``dg`` (an OracleDGModel of the ocean law) the two law methods of
+    src/Ocean/HydrostaticBoussinesq/hydrostatic_boussinesq_model.jl:
+    ``update_auxiliary_state!`` (:654-680): vertical cutoff filter on u, vertical exponential
+    filter on theta (real elements only); ``update_auxiliary_state_gradient!`` (:693-726):
+    ``A.w = -D.div_h u``, upward integrals of (w, -alpha_T theta) into (w, pkin), downward
+    integral of pkin, and the copy of w at the surface into wz0 of the whole column."""
+    from types import SimpleNamespace
+    law, grid = dg.law, dg.grid
+
+    class _T:           # FilterIndices
+        target_id = 0
+
+        def __init__(self, idx):
+            self.indices = tuple(idx)
+
+        def aux_offsets(self):
+            return (0, 0)
+
+    ilaw = integral_fields_law([(0, 1), (1, 3)], [1.0, -law.alpha_T], [1, 2], [2, 2], [2, 2],
+                               4, 8)
+    # the reverse integral touches pkin only (DownwardIntegrals has one variable)
+    rlaw = integral_fields_law([(0, 2)], [1.0], [2], [2], [2], 4, 8)
+    dg._ocean_keep = SimpleNamespace(ilaw=ilaw, rlaw=rlaw)
+    nv = grid.topology.stacksize
+
+    def pre(dgm, Q, t, which):
+        if which == "real":
+            apply_filter(Q, _T((1, 2)), grid, vert_filter, direction=VERTICAL)
+            apply_filter(Q, _T((4,)), grid, exp_filter, direction=VERTICAL)
+
+    def post(dgm, Q, t, which):
+        A, D = dgm.state_auxiliary, dgm.state_gradient_flux
+        e0, e1 = (0, grid.nreal) if which == "real" else (grid.nreal, grid.nelem)
+        if e1 <= e0:
+            return
+        A[e0:e1, 1, :] = -D[e0:e1, 0, :]
+        h = (e0 // nv, e1 // nv)
+        indefinite_stack_integral(ilaw, dgm.og, Q, A, horzelems=h)
+        reverse_indefinite_stack_integral(rlaw, dgm.og, Q, A, horzelems=h)
+        Nqh = grid.Nq[0] * grid.Nq[1]
+        data = A.reshape(grid.nelem // nv, nv, A.shape[1], grid.Nq[2], Nqh)
+        flat = data[h[0]:h[1], -1, 1, -1, :]                      # w at the top of the stack
+        data[h[0]:h[1], :, 3, :, :] = flat[:, None, None, :]
+
+    dg.update_auxiliary_state_hook = pre
+    dg.update_auxiliary_state_gradient_hook = post
 
 
 # ---- element filters (filter_oracle.c) --------------------------------------------------

@@ -127,3 +127,19 @@ def rising_bubble_setup(nx=20, ny=1, nz=20, N=4, rank=0, size=1):
                           boundary_conditions=(A.BC_ATMOS_DEFAULT, A.BC_ATMOS_DEFAULT),
                           param_set=ps)
     return law, grid
+
+
+def ocean_spindown_setup(Nx=5, Ny=5, Nz=8, N=4, rank=0, size=1):
+    """test/Ocean/HydrostaticBoussinesq/test_3D_spindown.jl:22-100: SimpleBox 1e6 x 1e6 x 400 m,
+    5 x 5 x 8 elements, N = 4, periodic in x and y, boundary (1, 2) in z, c_h = 1, alpha_T =
+    kappa = f = beta = 0, default viscosities; dt = 120 s, LSRK144, one day."""
+    O = cm.ocean
+    Lx, Ly, H = 1e6, 1e6, 400.0
+    problem = O.SimpleBox(Lx, Ly, H)
+    law = O.HydrostaticBoussinesqModel(problem, c_h=1.0, alpha_T=0.0, kappa_h=0.0, kappa_z=0.0,
+                                       f_o=0.0, beta=0.0)
+    rng = [np.linspace(0.0, Lx, Nx + 1), np.linspace(0.0, Ly, Ny + 1), np.linspace(-H, 0.0, Nz + 1)]
+    topl = M.StackedBrickTopology(rng, periodicity=(True, True, False),
+                                  boundary=((0, 0), (0, 0), (1, 2)), rank=rank, size=size)
+    grid = M.DiscontinuousSpectralElementGrid(topl, N)
+    return law, grid

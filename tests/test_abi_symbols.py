@@ -75,3 +75,10 @@ def test_stack_integral_desc_struct_matches_header_field_order():
     assert fields == [f[0] for f in cm._lib.CmdgStackIntegralDesc._fields_], fields
     txt = open(os.path.join(ROOT, "include", "cmdg.h")).read()
     assert "#define CMDG_STACK_MAXOUT %d" % cm._lib.STACK_MAXOUT in txt
+
+
+def test_rhs_hooks_struct_matches_header_field_order():
+    fields = _header_fields("cmdg_rhs_hooks")
+    assert fields == [f[0] for f in cm._lib.CmdgRhsHooks._fields_], fields
+    txt = open(os.path.join(ROOT, "include", "cmdg.h")).read()
+    assert "#define CMDG_MAX_HOOK_OPS %d" % cm._lib.MAX_HOOK_OPS in txt
