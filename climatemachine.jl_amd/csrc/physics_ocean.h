@@ -10,8 +10,10 @@
 // Parameter block: iparam[0] momentum advection, [1] tracer advection, [2] Coriolis (0 fixed
 // box f = -0, 1 rotating f = f_o, 2 beta plane), [6] nbc, [7..13] bc = velocity kind + 8 *
 // temperature kind (velocity 1 Impenetrable(NoSlip), 2 Impenetrable(FreeSlip), 3
-// Penetrable(FreeSlip); temperature 0 Insulating); dparam[0..10] = grav c_h c_z alpha_T nu_h
-// nu_z kappa_h kappa_z kappa_c f_o beta.
+// Penetrable(FreeSlip), 4 Impenetrable(KinematicStress), 5 Penetrable(KinematicStress);
+// temperature 0 Insulating, 1 TemperatureFlux -- stress and flux of the OceanGyre problem,
+// ocean_gyre.jl:84-115); dparam[0..10] = grav c_h c_z alpha_T nu_h nu_z kappa_h kappa_z kappa_c
+// f_o beta, [11..15] = tau_o rho_o L_y lambda_r theta_E.
 #pragma once
 #include "cmdg_common.h"
 
@@ -20,7 +22,7 @@ namespace cmdg {
 struct OceanParams {
     int madv, tadv, cor, nbc;
     int bc[8];
-    double grav, ch, cz, aT, nuh, nuz, kh, kz, kc, fo, beta;
+    double grav, ch, cz, aT, nuh, nuz, kh, kz, kc, fo, beta, tau_o, rho_o, Ly, lam_r, thE;
 };
 
 struct HydroBoussinesq {
@@ -58,6 +60,11 @@ struct HydroBoussinesq {
         p.kc = dp[8];
         p.fo = dp[9];
         p.beta = dp[10];
+        p.tau_o = dp[11];
+        p.rho_o = dp[12];
+        p.Ly = dp[13];
+        p.lam_r = dp[14];
+        p.thE = dp[15];
     }
 
     __device__ static void flux_first_order(const Params &m, double *F, const double *Q,
@@ -163,7 +170,7 @@ struct HydroBoussinesq {
                 QP[V] = -0.0;
                 auxP[AW] = -0.0;
             }
-        } else if (bv == 2) {  // Impenetrable(FreeSlip)
+        } else if (bv == 2 || bv == 4) {  // Impenetrable(FreeSlip); KinematicStress -> FreeSlip
             const double v[3] = {QM[U], QM[V], auxM[AW]};
             const double dn = kind == BS_FIRST
                                   ? (2 * n[0]) * v[0] + (2 * n[1]) * v[1] + (2 * n[2]) * v[2]
@@ -186,6 +193,14 @@ struct HydroBoussinesq {
             auxP[AW] = -auxM[AW];
 #pragma unroll
             for (int q = 0; q < 6; ++q) gfP[GNU + q] = gfM[GNU + q];
+        } else if (bv == 4 || bv == 5) {  // KinematicStress (bc_velocity.jl:218-289)
+            const double st[2] = {(m.tau_o / m.rho_o) * cos(auxM[AY] * M_PI / m.Ly), -0.0};
+            QP[U] = QM[U];
+            QP[V] = QM[V];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) gfP[GNU + d + 3 * c] = n[d] * st[c];
         } else {
             QP[U] = QM[U];
             QP[V] = QM[V];
@@ -196,8 +211,15 @@ struct HydroBoussinesq {
                 for (int d = 0; d < 3; ++d) gfP[GNU + d + 3 * c] = n[d] * -0.0;
         }
         QP[TH] = QM[TH];
+        if ((m.bc[bctag - 1] >> 3) == 1) {  // TemperatureFlux (bc_temperature.jl:66-88)
+            const double thr = m.thE * (1 - auxM[AY] / m.Ly);
+            const double fl = m.lam_r * (QM[TH] - thr);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) gfP[GKAPPA + d] = n[d] * -0.0;
+            for (int d = 0; d < 3; ++d) gfP[GKAPPA + d] = n[d] * fl;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) gfP[GKAPPA + d] = n[d] * -0.0;
+        }
         flux_second_order(m, F, QP, gfP, hypP, auxP, t);
     }
     __device__ static void boundary_state_divergence(const Params &, int, double *, double *,

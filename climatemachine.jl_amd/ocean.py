@@ -19,12 +19,14 @@ from scipy.linalg import expm
 from .balancelaws import PHYSICS_HYDROSTATIC_BOUSSINESQ
 from .mesh import filters as F
 
-__all__ = ["HydrostaticBoussinesqModel", "SimpleBox", "OceanBC", "IMPENETRABLE_NOSLIP",
-           "IMPENETRABLE_FREESLIP", "PENETRABLE_FREESLIP", "INSULATING",
-           "install_hydrostatic_boussinesq_hooks"]
+__all__ = ["HydrostaticBoussinesqModel", "SimpleBox", "OceanGyre", "OceanBC",
+           "IMPENETRABLE_NOSLIP", "IMPENETRABLE_FREESLIP", "PENETRABLE_FREESLIP",
+           "IMPENETRABLE_KINEMATIC_STRESS", "PENETRABLE_KINEMATIC_STRESS", "INSULATING",
+           "TEMPERATURE_FLUX", "install_hydrostatic_boussinesq_hooks"]
 
 IMPENETRABLE_NOSLIP, IMPENETRABLE_FREESLIP, PENETRABLE_FREESLIP = 1, 2, 3
-INSULATING = 0
+IMPENETRABLE_KINEMATIC_STRESS, PENETRABLE_KINEMATIC_STRESS = 4, 5
+INSULATING, TEMPERATURE_FLUX = 0, 1
 FIXED, ROTATING, BETA_PLANE = 0, 1, 2
 
 
@@ -58,6 +60,27 @@ class SimpleBox:
         return u0 + Ub / self.H, 0.0 * x, eta, 0.0 * x
 
 
+class OceanGyre:
+    """``OceanGyre{FT}(Lx, Ly, H; tau_o, lambda_r, theta_E, BC)`` (ocean_gyre.jl:14-37): wind
+    stress, beta-plane Coriolis force and temperature relaxation; BCs: no-slip insulating walls
+    (tag 1) and bottom (tag 2), penetrable surface with kinematic stress and temperature flux
+    (tag 3)."""
+    rotation = BETA_PLANE
+
+    def __init__(self, Lx, Ly, H, tau_o=1e-1, lambda_r=4 / 86400, theta_E=10.0,
+                 BC=(OceanBC(IMPENETRABLE_NOSLIP), OceanBC(IMPENETRABLE_NOSLIP),
+                     OceanBC(PENETRABLE_KINEMATIC_STRESS, TEMPERATURE_FLUX))):
+        self.Lx, self.Ly, self.H = float(Lx), float(Ly), float(H)
+        self.tau_o, self.lambda_r, self.theta_E = tau_o, lambda_r, theta_E
+        self.boundary_conditions = tuple(BC)
+
+    def init_state(self, m, x, y, z, t):
+        """``ocean_init_state!`` (ocean_gyre.jl:51-66)."""
+        th = (5 + 4 * np.cos(y * np.pi / self.Ly)) * (1 + z / self.H)
+        zero = -0.0 * np.ones_like(x)
+        return zero, zero.copy(), zero.copy(), th
+
+
 class HydrostaticBoussinesqModel:
     physics_id = PHYSICS_HYDROSTATIC_BOUSSINESQ
     ns, naux, ngrad, ngradflux, ngradlap, nhyper = 4, 8, 5, 10, 0, 0
@@ -85,6 +108,9 @@ class HydrostaticBoussinesqModel:
         dp = np.zeros(32)
         dp[0:11] = [self.grav, self.c_h, self.c_z, self.alpha_T, self.nu_h, self.nu_z,
                     self.kappa_h, self.kappa_z, self.kappa_c, self.f_o, self.beta]
+        pr = self.problem
+        dp[11:16] = [getattr(pr, "tau_o", 0.0), self.rho_o, pr.Ly, getattr(pr, "lambda_r", 0.0),
+                     getattr(pr, "theta_E", 0.0)]
         return ip, dp
 
     def init_state_auxiliary(self, grid):

@@ -14,8 +14,11 @@
  *   iparam[0]=momentum advection (NonLinearAdvectionTerm) [1]=tracer advection
  *   [2]=Coriolis: 0 SimpleBox{Fixed} (f = -0), 1 SimpleBox{Rotating} (f = f_o), 2 beta plane
  *   [6]=nbc [7..13]=bc of tag 1..7: velocity kind + 8 * temperature kind, velocity kinds
- *   1 Impenetrable(NoSlip) 2 Impenetrable(FreeSlip) 3 Penetrable(FreeSlip); temperature 0 Insulating
+ *   1 Impenetrable(NoSlip) 2 Impenetrable(FreeSlip) 3 Penetrable(FreeSlip)
+ *   4 Impenetrable(KinematicStress) 5 Penetrable(KinematicStress); temperature 0 Insulating,
+ *   1 TemperatureFlux (stress and flux of the OceanGyre problem, ocean_gyre.jl:84-115)
  *   dparam[0..10] = grav c_h c_z alpha_T nu_h nu_z kappa_h kappa_z kappa_c f_o beta
+ *   dparam[11..15] = tau_o rho_o L_y lambda_r theta_E
  */
 #include <math.h>
 #include <stdlib.h>
@@ -24,12 +27,12 @@
 
 typedef struct {
     int madv, tadv, cor, nbc, bc[8];
-    double grav, ch, cz, aT, nuh, nuz, kh, kz, kc, fo, beta;
+    double grav, ch, cz, aT, nuh, nuz, kh, kz, kc, fo, beta, tau_o, rho_o, Ly, lam_r, thE;
 } ocean_t;
 enum { U = 0, V = 1, ETA = 2, TH = 3 };                 /* prognostic */
 enum { AY = 0, AW = 1, APKIN = 2, AWZ0 = 3 };           /* auxiliary */
 enum { GDIVH = 0, GNU = 1, GKAPPA = 7 };                /* gradient flux */
-enum { BV_NOSLIP = 1, BV_FREESLIP = 2, BV_PENETRABLE = 3 };
+enum { BV_NOSLIP = 1, BV_FREESLIP = 2, BV_PENETRABLE = 3, BV_STRESS = 4, BV_PEN_STRESS = 5 };
 
 static void oc_flux1(const void *p_, double *F, const double *Q, const double *aux, double t, int dir)
 {
@@ -140,7 +143,7 @@ static void oc_bstate(const void *p_, int kind, int bctag, double *QP, double *a
             QP[V] = -0.0;
             auxP[AW] = -0.0;
         }
-    } else if (bv == BV_FREESLIP) {
+    } else if (bv == BV_FREESLIP || bv == BV_STRESS) { /* KinematicStress -> FreeSlip here */
         const double v[3] = {QM[U], QM[V], auxM[AW]};
         double vp[3];
         if (kind == ORC_BS_FIRST) { /* v - ((2 n) . v) n */
@@ -171,6 +174,13 @@ static void oc_bflux2(const void *p_, int bctag, double *F, double *QP, double *
         QP[V] = -QM[V];
         auxP[AW] = -auxM[AW];
         for (int q = 0; q < 6; ++q) gfP[GNU + q] = gfM[GNU + q];
+    } else if (bv == BV_STRESS || bv == BV_PEN_STRESS) {
+        /* kinematic_stress(p::OceanGyre, y, rho) = [(tau_o / rho) cos(y pi / L_y), -0] */
+        const double st[2] = {(m->tau_o / m->rho_o) * cos(auxM[AY] * M_PI / m->Ly), -0.0};
+        QP[U] = QM[U];
+        QP[V] = QM[V];
+        for (int c = 0; c < 2; ++c)
+            for (int d = 0; d < 3; ++d) gfP[GNU + d + 3 * c] = n[d] * st[c];
     } else {
         QP[U] = QM[U];
         QP[V] = QM[V];
@@ -179,7 +189,13 @@ static void oc_bflux2(const void *p_, int bctag, double *F, double *QP, double *
             for (int d = 0; d < 3; ++d) gfP[GNU + d + 3 * c] = n[d] * -0.0;
     }
     QP[TH] = QM[TH];
-    for (int d = 0; d < 3; ++d) gfP[GKAPPA + d] = n[d] * -0.0;
+    if ((m->bc[bctag - 1] >> 3) == 1) { /* TemperatureFlux: surface_flux(p, y, theta) */
+        const double thr = m->thE * (1 - auxM[AY] / m->Ly);
+        const double fl = m->lam_r * (QM[TH] - thr);
+        for (int d = 0; d < 3; ++d) gfP[GKAPPA + d] = n[d] * fl;
+    } else {
+        for (int d = 0; d < 3; ++d) gfP[GKAPPA + d] = n[d] * -0.0;
+    }
     oc_flux2(p_, F, QP, gfP, hypP, auxP, t);
 }
 static void oc_bdiv(const void *p, int b, double *gP, double *aP, const double *n, const double *gM,
@@ -201,6 +217,7 @@ orc_physics *orc_ocean_new(const int *ip, const double *dp, int nf_first)
     for (int i = 0; i < 7; ++i) m->bc[i] = ip[7 + i];
     m->grav = dp[0]; m->ch = dp[1]; m->cz = dp[2]; m->aT = dp[3]; m->nuh = dp[4]; m->nuz = dp[5];
     m->kh = dp[6]; m->kz = dp[7]; m->kc = dp[8]; m->fo = dp[9]; m->beta = dp[10];
+    m->tau_o = dp[11]; m->rho_o = dp[12]; m->Ly = dp[13]; m->lam_r = dp[14]; m->thE = dp[15];
     ph->ns = 4;
     ph->naux = 8;
     ph->ngrad = 5;

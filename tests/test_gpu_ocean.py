@@ -5,8 +5,8 @@ against the oracle, multi-rank against single-rank, and the reference's regressi
 import numpy as np
 import pytest
 
-from helpers import ocean_spindown_setup, rel_linf
-from test_ocean_oracle import GOLD, check_against_refvals
+from helpers import ocean_gyre_setup, ocean_spindown_setup, rel_linf
+from test_ocean_oracle import GOLD, check_against_refvals, check_gyre_refvals
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-12
@@ -128,6 +128,37 @@ def test_spindown_reference_regression_on_the_gpu(cm, torch):
     assert err < 0.005
     assert abs(err - GOLD["error_printed_by_reference"]) < 1e-10
     check_against_refvals(Q.cpu().numpy(), dg.state_auxiliary.cpu().numpy(), rtol=5e-12)
+    dg.set_rhs_hooks()
+    for f in keep:
+        f.close()
+    dg.close()
+
+
+def test_ocean_gyre_short_reference_regression_on_the_gpu(cm, oracle, torch):
+    """test_ocean_gyre_short.jl end to end on the device + tendency parity with the oracle for
+    the wind-stress / temperature-flux / no-slip boundary conditions."""
+    O, F = cm.ocean, cm.mesh.filters
+    law, grid = ocean_gyre_setup()
+    dg = cm.dgmodel.DGModel(law, grid)
+    keep = O.install_hydrostatic_boussinesq_hooks(dg)
+    odg = oracle.OracleDGModel(law, grid)
+    oracle.hydrostatic_boussinesq_hooks(odg, F.CutoffFilter(grid, 3), F.ExponentialFilter(grid, 1, 8))
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    rng = np.random.default_rng(2)
+    Q0[:, 0:2] = 0.05 * rng.standard_normal(Q0[:, 0:2].shape)
+    Q0[:, 2] = 0.1 * rng.standard_normal(Q0[:, 2].shape)
+    To = np.zeros_like(Q0)
+    odg(To, Q0.copy(), 0.0, 1.0, 0.0)
+    Tg = _gpu(torch, np.zeros_like(Q0))
+    dg(Tg, _gpu(torch, Q0), 0.0, 1.0, 0.0)
+    Tn = Tg.cpu().numpy()
+    for s in range(4):
+        assert rel_linf(Tn[:, s], To[:, s]) < TOL, s
+    Q = dg.init_ode_state(0.0)
+    solver = cm.odesolvers.LSRK144NiegemannDiehlBusch(dg, Q, dt=120.0)
+    solver.dostep(Q, nsteps=30)
+    dg.synchronize()
+    assert check_gyre_refvals(Q.cpu().numpy(), dg.state_auxiliary.cpu().numpy()) == 32
     dg.set_rhs_hooks()
     for f in keep:
         f.close()

@@ -11,9 +11,10 @@ import numpy as np
 import pytest
 
 from cmdg_loader import cm
-from helpers import ocean_spindown_setup
+from helpers import ocean_gyre_setup, ocean_spindown_setup
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ocean_spindown_refvals.json")))
+GYRE = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ocean_gyre_short_refvals.json")))
 F = cm.mesh.filters
 
 
@@ -65,3 +66,36 @@ def test_spindown_matches_reference_statecheck(oracle):
     check_against_refvals(Q, dg.state_auxiliary, rtol=5e-12)
     # v stays at rounding level, theta and pkin identically zero (alpha_T = 0)
     assert np.abs(Q[:, 1]).max() < 1e-12 and not Q[:, 3].any() and not dg.state_auxiliary[:, 2].any()
+
+
+def check_gyre_refvals(Q, aux, rtol=2e-12):
+    """all four statistics of the seven live fields against the `short` table; values that are
+    small by cancellation (means, theta at the sea floor) are compared on the field's scale."""
+    fields = {"u[1]": Q[:, 0], "u[2]": Q[:, 1], "η": Q[:, 2], "θ": Q[:, 3], "y": aux[:, 0],
+              "w": aux[:, 1], "pkin": aux[:, 2], "wz0": aux[:, 3]}
+    n = 0
+    for lab, name, rmin, rmax, rmean, rstd in GYRE["short"]:
+        if name not in fields:
+            continue
+        st = statecheck(fields[name])
+        scale = max(abs(rmin), abs(rmax))
+        for got, ref in zip(st, (rmin, rmax, rmean, rstd)):
+            assert abs(got - ref) <= rtol * max(abs(ref), 0.05 * scale), (name, got, ref)
+            n += 1
+    return n
+
+
+def test_ocean_gyre_short_matches_reference_statecheck(oracle):
+    """test_ocean_gyre_short.jl: wind stress + temperature flux at the surface, no-slip walls,
+    beta-plane Coriolis force, stratified theta with convective adjustment; 30 LSRK144 steps."""
+    law, grid = ocean_gyre_setup()
+    dg = oracle.OracleDGModel(law, grid)
+    oracle.hydrostatic_boussinesq_hooks(dg, F.CutoffFilter(grid, 3), F.ExponentialFilter(grid, 1, 8))
+    Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
+    RKA, RKB, RKC = cm.odesolvers.LSRK144_COEFFICIENTS
+    dQ = np.zeros_like(Q)
+    t = 0.0
+    for _ in range(30):
+        oracle.lsrk_step(dg, Q, dQ, t, 120.0, RKA, RKB, RKC)
+        t += 120.0
+    assert check_gyre_refvals(Q, dg.state_auxiliary) == 32
