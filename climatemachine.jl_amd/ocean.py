@@ -19,7 +19,7 @@ from scipy.linalg import expm
 from .balancelaws import PHYSICS_HYDROSTATIC_BOUSSINESQ
 from .mesh import filters as F
 
-__all__ = ["HydrostaticBoussinesqModel", "SimpleBox", "OceanGyre", "OceanBC",
+__all__ = ["HydrostaticBoussinesqModel", "SimpleBox", "OceanGyre", "HomogeneousBox", "OceanBC",
            "IMPENETRABLE_NOSLIP", "IMPENETRABLE_FREESLIP", "PENETRABLE_FREESLIP",
            "IMPENETRABLE_KINEMATIC_STRESS", "PENETRABLE_KINEMATIC_STRESS", "INSULATING",
            "TEMPERATURE_FLUX", "install_hydrostatic_boussinesq_hooks"]
@@ -79,6 +79,20 @@ class OceanGyre:
         th = (5 + 4 * np.cos(y * np.pi / self.Ly)) * (1 + z / self.H)
         zero = -0.0 * np.ones_like(x)
         return zero, zero.copy(), zero.copy(), th
+
+
+class HomogeneousBox(OceanGyre):
+    """``HomogeneousBox{FT}(Lx, Ly, H; tau_o, BC)`` (homogeneous_box.jl:15-54): wind stress on
+    a box of constant temperature."""
+
+    def __init__(self, Lx, Ly, H, tau_o=1e-1,
+                 BC=(OceanBC(IMPENETRABLE_NOSLIP), OceanBC(IMPENETRABLE_NOSLIP),
+                     OceanBC(PENETRABLE_KINEMATIC_STRESS, INSULATING))):
+        OceanGyre.__init__(self, Lx, Ly, H, tau_o=tau_o, lambda_r=0.0, theta_E=0.0, BC=BC)
+
+    def init_state(self, m, x, y, z, t):
+        zero = 0.0 * x
+        return zero, zero.copy(), zero.copy(), zero + 20.0
 
 
 class HydrostaticBoussinesqModel:

@@ -159,3 +159,19 @@ def ocean_gyre_setup(Nx=5, Ny=5, Nz=5, N=4, rank=0, size=1):
                                   boundary=((1, 1), (1, 1), (2, 3)), rank=rank, size=size)
     grid = M.DiscontinuousSpectralElementGrid(topl, N)
     return law, grid
+
+
+def ocean_windstress_setup(Nx=5, Ny=5, Nz=5, N=4, rank=0, size=1):
+    """test/Ocean/HydrostaticBoussinesq/test_windstress_short.jl (explicit run): HomogeneousBox
+    1e6 x 1e6 x 400 m, 5^3 elements, no-slip walls (tag 1), free-slip bottom (tag 2), penetrable
+    surface with kinematic stress (tag 3), all insulating; dt = 180 s, LSRK144, one hour."""
+    O = cm.ocean
+    Lx, Ly, H = 1e6, 1e6, 400.0
+    BC = (O.OceanBC(O.IMPENETRABLE_NOSLIP), O.OceanBC(O.IMPENETRABLE_FREESLIP),
+          O.OceanBC(O.PENETRABLE_KINEMATIC_STRESS))
+    law = O.HydrostaticBoussinesqModel(O.HomogeneousBox(Lx, Ly, H, BC=BC), c_h=np.sqrt(9.81 * H))
+    rng = [np.linspace(0.0, Lx, Nx + 1), np.linspace(0.0, Ly, Ny + 1), np.linspace(-H, 0.0, Nz + 1)]
+    topl = M.StackedBrickTopology(rng, periodicity=(False, False, False),
+                                  boundary=((1, 1), (1, 1), (2, 3)), rank=rank, size=size)
+    grid = M.DiscontinuousSpectralElementGrid(topl, N)
+    return law, grid

@@ -5,8 +5,8 @@ against the oracle, multi-rank against single-rank, and the reference's regressi
 import numpy as np
 import pytest
 
-from helpers import ocean_gyre_setup, ocean_spindown_setup, rel_linf
-from test_ocean_oracle import GOLD, check_against_refvals, check_gyre_refvals
+from helpers import ocean_gyre_setup, ocean_spindown_setup, ocean_windstress_setup, rel_linf
+from test_ocean_oracle import GOLD, WIND, check_against_refvals, check_gyre_refvals
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-12
@@ -159,6 +159,23 @@ def test_ocean_gyre_short_reference_regression_on_the_gpu(cm, oracle, torch):
     solver.dostep(Q, nsteps=30)
     dg.synchronize()
     assert check_gyre_refvals(Q.cpu().numpy(), dg.state_auxiliary.cpu().numpy()) == 32
+    dg.set_rhs_hooks()
+    for f in keep:
+        f.close()
+    dg.close()
+
+
+def test_windstress_short_reference_regression_on_the_gpu(cm, torch):
+    O = cm.ocean
+    law, grid = ocean_windstress_setup()
+    dg = cm.dgmodel.DGModel(law, grid)
+    keep = O.install_hydrostatic_boussinesq_hooks(dg)
+    Q = dg.init_ode_state(0.0)
+    solver = cm.odesolvers.LSRK144NiegemannDiehlBusch(dg, Q, dt=180.0)
+    solver.dostep(Q, nsteps=20)
+    dg.synchronize()
+    table = [r for r in WIND["explicit_cpu"] if r[1] != "θ"]
+    assert check_gyre_refvals(Q.cpu().numpy(), dg.state_auxiliary.cpu().numpy(), table=table, rtol=2e-11) == 28
     dg.set_rhs_hooks()
     for f in keep:
         f.close()

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from cmdg_loader import cm
-from helpers import ocean_gyre_setup, ocean_spindown_setup
+from helpers import ocean_gyre_setup, ocean_spindown_setup, ocean_windstress_setup
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ocean_spindown_refvals.json")))
 GYRE = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ocean_gyre_short_refvals.json")))
@@ -68,19 +68,24 @@ def test_spindown_matches_reference_statecheck(oracle):
     assert np.abs(Q[:, 1]).max() < 1e-12 and not Q[:, 3].any() and not dg.state_auxiliary[:, 2].any()
 
 
-def check_gyre_refvals(Q, aux, rtol=2e-12):
+WIND = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                   "ocean_windstress_short_refvals.json")))
+
+
+def check_gyre_refvals(Q, aux, rtol=2e-12, table=None):
     """all four statistics of the seven live fields against the `short` table; values that are
     small by cancellation (means, theta at the sea floor) are compared on the field's scale."""
     fields = {"u[1]": Q[:, 0], "u[2]": Q[:, 1], "η": Q[:, 2], "θ": Q[:, 3], "y": aux[:, 0],
               "w": aux[:, 1], "pkin": aux[:, 2], "wz0": aux[:, 3]}
     n = 0
-    for lab, name, rmin, rmax, rmean, rstd in GYRE["short"]:
+    for lab, name, rmin, rmax, rmean, rstd in (table or GYRE["short"]):
         if name not in fields:
             continue
         st = statecheck(fields[name])
         scale = max(abs(rmin), abs(rmax))
-        for got, ref in zip(st, (rmin, rmax, rmean, rstd)):
-            assert abs(got - ref) <= rtol * max(abs(ref), 0.05 * scale), (name, got, ref)
+        for k, (got, ref) in enumerate(zip(st, (rmin, rmax, rmean, rstd))):
+            floor = scale if k == 2 else 0.05 * scale     # the mean is a cancelling sum
+            assert abs(got - ref) <= rtol * max(abs(ref), floor), (name, got, ref)
             n += 1
     return n
 
@@ -99,3 +104,23 @@ def test_ocean_gyre_short_matches_reference_statecheck(oracle):
         oracle.lsrk_step(dg, Q, dQ, t, 120.0, RKA, RKB, RKC)
         t += 120.0
     assert check_gyre_refvals(Q, dg.state_auxiliary) == 32
+
+
+def test_windstress_short_matches_reference_statecheck(oracle):
+    """explicit run of test_windstress_short.jl: 20 LSRK144 steps of 180 s."""
+    law, grid = ocean_windstress_setup()
+    dg = oracle.OracleDGModel(law, grid)
+    oracle.hydrostatic_boussinesq_hooks(dg, F.CutoffFilter(grid, 3), F.ExponentialFilter(grid, 1, 8))
+    Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
+    RKA, RKB, RKC = cm.odesolvers.LSRK144_COEFFICIENTS
+    dQ = np.zeros_like(Q)
+    t = 0.0
+    for _ in range(20):
+        oracle.lsrk_step(dg, Q, dQ, t, 180.0, RKA, RKB, RKC)
+        t += 180.0
+    table = [r for r in WIND["explicit_cpu"] if r[1] != "θ"]
+    # observed: 1e-13 except wz0 (surface w, small by cancellation: 7e-12); the reference's own
+    # CPU and GPU tables differ by 1e-11 in two entries (test_windstress_refvals.jl:47-49)
+    assert check_gyre_refvals(Q, dg.state_auxiliary, table=table, rtol=2e-11) == 28
+    # theta stays 20 to rounding (the reference's std of theta is 2.6e-13 and unchecked)
+    assert np.abs(Q[:, 3] - 20.0).max() < 1e-11
