@@ -52,6 +52,72 @@ class HomogeneousBC:
         return 1 << (self.order + 4)
 
 
+class NoFlowBC:
+    """``NoFlowBC`` of test/Numerics/DGMethods/advection_diffusion/advection_sphere.jl:118-132:
+    the plus-side advection velocity is the negative of the minus side."""
+    bit = 1 << 8
+
+
+class SolidBodyRotation:
+    """``SolidBodyRotation`` (advection_sphere.jl:28-55): one revolution per unit time about
+    the z axis on a spherical shell; the state is a Gaussian in longitude / latitude."""
+    problem_id = 5           # host-only problem: the kernels need no data from it
+
+    def dparam(self):
+        return np.zeros(32)
+
+    @staticmethod
+    def _lonlat(coord):
+        r = np.sqrt(coord[0] ** 2 + coord[1] ** 2 + coord[2] ** 2)
+        return np.arctan2(coord[1], coord[0]), np.arcsin(coord[2] / r), r
+
+    def init_velocity_diffusion(self, law, aux, coord):
+        lam, phi, r = self._lonlat(coord)
+        ul = 2 * np.pi * np.cos(phi) * r
+        up = 0.0
+        aux[:, law.off_u + 0, :] = -ul * np.sin(lam) - up * np.cos(lam) * np.sin(phi)
+        aux[:, law.off_u + 1, :] = +ul * np.cos(lam) - up * np.sin(lam) * np.sin(phi)
+        aux[:, law.off_u + 2, :] = +up * np.cos(phi)
+
+    def initial_condition(self, coord, t):
+        lam, phi, _ = self._lonlat(coord)
+        return np.exp(-((3 * lam) ** 2 + (3 * phi) ** 2))
+
+    finaltime = 1.0
+    u_scale = 2 * np.pi
+
+
+class DiffusionSphere:
+    """``DiffusionSphere`` of test/Numerics/DGMethods/advection_diffusion/
+    diffusion_hyperdiffusion_sphere.jl:25-55.  The reference runs it as a two-equation law
+    (equation 1: ``D = mu I``, ``H = 0``; equation 2: ``D = 0``, ``H = mu I``); the equations do
+    not couple, so each is run here as its own single-equation law (``hyper`` selects which)
+    and carries the l = 2, m = 1 spherical harmonic decaying at its analytic rate."""
+    problem_id = 6           # host-only problem
+
+    def __init__(self, hyper, mu=1 / 10000):
+        self.hyper, self.mu = bool(hyper), mu
+
+    def dparam(self):
+        return np.zeros(32)
+
+    def init_velocity_diffusion(self, law, aux, coord):
+        I = (self.mu * np.eye(3)).flatten(order="F")
+        if law.diffusion:
+            aux[:, law.off_D:law.off_D + 9, :] = I[None, :, None]
+        if law.hyperdiffusion:
+            aux[:, law.off_H:law.off_H + 9, :] = I[None, :, None]
+
+    def initial_condition(self, coord, t):
+        x, y, z = coord
+        r = np.sqrt(x * x + y * y + z * z)
+        th = np.arctan2(np.sqrt(x ** 2 + y ** 2), z)
+        ph = np.arctan2(y, x)
+        rho0 = np.cos(ph) * np.sin(th) * np.cos(th)
+        c = 2 * (2 + 1) / r ** 2
+        return rho0 * np.exp(-(c ** 2 if self.hyper else c) * self.mu * t)
+
+
 class Pseudo1D:
     """``Pseudo1D{n, alpha, beta, mu, delta}`` (pseudo1D_advection_diffusion.jl:28-68)."""
     problem_id = 0

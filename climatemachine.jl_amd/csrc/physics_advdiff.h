@@ -7,7 +7,8 @@
 // Parameter block (cmdg_desc.iparam / dparam):
 //   iparam[0]=num_equations (1)  [1]=advection [2]=diffusion [3]=hyperdiffusion
 //   iparam[4]=flux_bc [5]=problem [6]=nbc [7..13]=bc bitmask of boundary tag 1..7
-//   bc bit b: InhomogeneousBC{b} for b=0..3, HomogeneousBC{b-4} for b=4..7
+//   bc bit b: InhomogeneousBC{b} for b=0..3, HomogeneousBC{b-4} for b=4..7, bit 8 NoFlowBC
+//   (advection_sphere.jl:118-132)
 //   dparam: Pseudo1D n[3], alpha, beta, mu, delta | ConstantHyperDiffusion D[9], dim, dir
 //
 // Grad-type locals are 3 x nvar column-major: g[d + 3*s] (vars_wrappers.jl:52).
@@ -153,12 +154,21 @@ struct AdvDiff {
             ws[0] = 0.0;
     }
     // boundary_state!(nf, bcs, m, stateP, auxP, nM, stateM, auxM, t, _...)  (:402-428)
-    __device__ static void boundary_state(const Params &m, int, int bctag, double *QP,
+    __device__ static void boundary_state(const Params &m, int kind, int bctag, double *QP,
                                           double *auxP, const double *, const double *QM,
-                                          const double *, double t, const double *,
+                                          const double *auxM, double t, const double *,
                                           const double *)
     {
         const int bc = m.bc[bctag - 1];
+        if (bc & (1 << 8)) {  // NoFlowBC, first-order (Rusanov) flux only
+            if constexpr (ADV) {
+                if (kind == BS_FIRST) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) auxP[OU + d] = -auxM[OU + d];
+                }
+            }
+            return;
+        }
         if (bc & BC_INHOM(0))
             QP[0] = problem_rho(m, auxP, t);
         else if (bc & BC_ANY(1))

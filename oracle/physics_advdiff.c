@@ -11,7 +11,8 @@
  * Parameter block (shared *data* contract with the product's descriptor):
  *   iparam[0]=num_equations (1)  [1]=advection [2]=diffusion [3]=hyperdiffusion
  *   iparam[4]=flux_bc [5]=problem [6]=nbc [7..13]=bc bitmask of tag 1..7
- *   bc bit b: InhomogeneousBC{b} for b=0..3, HomogeneousBC{b-4} for b=4..7
+ *   bc bit b: InhomogeneousBC{b} for b=0..3, HomogeneousBC{b-4} for b=4..7, bit 8 NoFlowBC
+ *   (advection_sphere.jl:118-132)
  *   dparam: problem parameters (see each problem)
  */
 #include <math.h>
@@ -152,8 +153,13 @@ static void ad_bstate(const void *p, int kind, int bctag, double *QP, double *au
                       const double *aux1)
 {
     const advdiff_t *m = (const advdiff_t *)p;
-    (void)kind; (void)n; (void)auxM; (void)Q1; (void)aux1;
+    (void)n; (void)Q1; (void)aux1;
     const int bc = m->bc[bctag - 1];
+    if (bc & (1 << 8)) { /* NoFlowBC: boundary_state!(::RusanovNumericalFlux, ...) only */
+        if (kind == ORC_BS_FIRST && m->adv)
+            for (int d = 0; d < 3; ++d) auxP[m->ou + d] = -auxM[m->ou + d];
+        return;
+    }
     if (bc & BC_INHOM(0))
         QP[0] = problem_rho(m, auxP, t);
     else if (bc & BC_ANY(1))

@@ -175,3 +175,34 @@ def ocean_windstress_setup(Nx=5, Ny=5, Nz=5, N=4, rank=0, size=1):
                                   boundary=((1, 1), (1, 1), (2, 3)), rank=rank, size=size)
     grid = M.DiscontinuousSpectralElementGrid(topl, N)
     return law, grid
+
+
+def advection_sphere_setup(level=1, N=4, rank=0, size=1):
+    """test/Numerics/DGMethods/advection_diffusion/advection_sphere.jl:303-430
+    (SolidBodyRotation, LSRK144 at CFL 5): cubed sphere of 2^(level-1) * 2 elements per edge,
+    one element between R = 1 and R = 2, NoFlowBC on both shells, advection only, Rusanov."""
+    nh = 2 ** (level - 1) * 2
+    topl = M.StackedCubedSphereTopology(nh, np.linspace(1.0, 2.0, 2), rank=rank, size=size)
+    grid = M.DiscontinuousSpectralElementGrid(topl, N, meshwarp=M.equiangular_cubed_sphere_warp)
+    prob = BL.SolidBodyRotation()
+    law = BL.AdvectionDiffusion(3, prob, (BL.NoFlowBC(),), diffusion=False)
+    dx = M.grids.min_node_distance(grid, 1)
+    dt = 5.0 * dx / prob.u_scale
+    dt = 1.0 / np.ceil(1.0 / dt)
+    return law, grid, dt
+
+
+def diffusion_sphere_setup(level=1, hyper=False, N=3, rank=0, size=1):
+    """diffusion_hyperdiffusion_sphere.jl:99-270: cubed sphere of 2^(level-1) * 4 elements per
+    edge, N = 3, shell [1, 2] without boundary tags, diffusion_direction horizontal, central
+    fluxes, LSRK54 with dt = 300 dx^4."""
+    Ne = 2 ** (level - 1) * 4
+    topl = M.StackedCubedSphereTopology(Ne, np.linspace(1.0, 2.0, 2), boundary=(0, 0),
+                                        rank=rank, size=size)
+    grid = M.DiscontinuousSpectralElementGrid(topl, N, meshwarp=M.equiangular_cubed_sphere_warp)
+    law = BL.AdvectionDiffusion(3, BL.DiffusionSphere(hyper), (), advection=False,
+                                diffusion=not hyper, hyperdiffusion=hyper)
+    dx = M.grids.min_node_distance(grid)
+    dt = 300 * dx ** 4
+    dt = 2.0 / np.ceil(2.0 / dt)
+    return law, grid, dt
