@@ -85,6 +85,7 @@ SYMBOLS = [
     ("cmdg_comm_selftest", C.c_int, [_vp, _i64]),
     ("cmdg_comm_connect_local", C.c_int, [_vp, _i32]),
     ("cmdg_group_rhs", C.c_int, [_vp, _i32, _vp, _vp, _d, _d, _d]),
+    ("cmdg_group_halo", C.c_int, [_vp, _i32, _vp, _i32]),
     ("cmdg_group_lsrk_run", C.c_int, [_vp, _i32, _vp, _vp, _d, _d, _i64, _i32, _vp, _vp, _vp]),
     ("cmdg_norm2_local", C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     ("cmdg_distance2_local", C.c_int, [_vp, _vp, _vp, _i32, _vp]),

@@ -230,7 +230,10 @@ class DryAtmosModel:
     def __init__(self, init_state, orientation=ORIENT_SPHERICAL, ref_state=None,
                  subtract_off=True, viscosity=0.0, dynamic_viscosity=False,
                  hyperdiffusion_timescale=None, sources=0, boundary_conditions=(),
-                 param_set=None, smagorinsky=None):
+                 param_set=None, smagorinsky=None, discrete_hydrostatic_balance=False):
+        # ref_state.jl:150-175: rho_ref = -k . grad(p_ref) / (k . grad Phi) with the DG gradient of
+        # the reference pressure.  Needs the operator (device or oracle); off = analytic density
+        self.discrete_hydrostatic_balance = bool(discrete_hydrostatic_balance)
         self.C_smag = smagorinsky
         if smagorinsky is not None:
             assert hyperdiffusion_timescale is None and orientation != ORIENT_NONE
@@ -343,6 +346,23 @@ class DryAtmosModel:
             c2 = np.sqrt(vg[:, G._x1xi2] ** 2 + vg[:, G._x2xi2] ** 2 + vg[:, G._x3xi2] ** 2)
             aux[:, self.off_delta, :] = (c1 * 2 / N[0] + c2 * 2 / N[1]) / 2
         return aux
+
+    def rebalance_reference_state(self, grid, aux, gradp):
+        """``ref_state_init_density_from_pressure!`` + ``ref_state_finalize_init!``
+        (ref_state.jl:83-135) on the real elements: the density that balances the DG gradient
+        of the reference pressure, then T and rho e consistent with (rho, p)."""
+        ps, nr = self.ps, grid.nreal
+        gP = aux[:nr, self.off_phi + 1:self.off_phi + 4, :]
+        k = gP / ps.grav
+        num = -(k[:, 0] * gradp[:nr, 0] + k[:, 1] * gradp[:nr, 1] + k[:, 2] * gradp[:nr, 2])
+        den = k[:, 0] * gP[:, 0] + k[:, 1] * gP[:, 1] + k[:, 2] * gP[:, 2]
+        rho = num / den
+        o = self.off_ref
+        p = aux[:nr, o + 1, :]
+        T = p / (ps.R_d * rho)
+        aux[:nr, o + 0, :] = rho
+        aux[:nr, o + 2, :] = T
+        aux[:nr, o + 3, :] = rho * (0.0 + aux[:nr, self.off_phi, :] + ps.cv_d * (T - ps.T_0))
 
     def init_state_prognostic(self, grid, aux, t):
         Q = np.zeros((grid.nelem, self.ns, grid.Np))

@@ -21,6 +21,7 @@ RusanovNumericalFlux, CentralNumericalFluxFirstOrder = 0, 1
 PHYSICS_ADVECTION_DIFFUSION = 1
 PHYSICS_DRY_ATMOS = 2
 PHYSICS_HYDROSTATIC_BOUSSINESQ = 3
+PHYSICS_PRESSURE_GRADIENT = 4
 
 __all__ = [
     "EveryDirection", "HorizontalDirection", "VerticalDirection",
@@ -50,6 +51,25 @@ class HomogeneousBC:
     @property
     def bit(self):
         return 1 << (self.order + 4)
+
+
+class PressureGradientModel:
+    """``PressureGradientModel`` (src/Atmos/Model/ref_state.jl:196-233): tendency = DG gradient
+    of the auxiliary field ``p``."""
+    physics_id = PHYSICS_PRESSURE_GRADIENT
+    ns, naux, ngrad, ngradflux, ngradlap, nhyper = 3, 1, 0, 0, 0, 0
+
+    def __init__(self, p):
+        self._p = np.ascontiguousarray(p[:, None, :], dtype=np.float64)
+
+    def descriptor(self):
+        return np.zeros(16, dtype=np.int32), np.zeros(32)
+
+    def init_state_auxiliary(self, grid):
+        return self._p
+
+    def init_state_prognostic(self, grid, aux, t):
+        return np.zeros((grid.nelem, 3, grid.Np))
 
 
 class NoFlowBC:

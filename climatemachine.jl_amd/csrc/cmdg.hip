@@ -835,6 +835,7 @@ int cmdg_physics_counts(int32_t physics_id, const int32_t *iparam, int32_t out[6
     case CMDG_PHYSICS_ADVECTION_DIFFUSION: return counts_advdiff(iparam, out);
     case CMDG_PHYSICS_DRY_ATMOS: return counts_atmos(iparam, out);
     case CMDG_PHYSICS_HYDROSTATIC_BOUSSINESQ: return counts_ocean(iparam, out);
+    case CMDG_PHYSICS_PRESSURE_GRADIENT: return counts_pgrad(iparam, out);
     default: return CMDG_ERR_UNSUPPORTED;
     }
 }
@@ -858,6 +859,7 @@ int cmdg_create(const cmdg_desc *d, cmdg_handle *out)
     case CMDG_PHYSICS_ADVECTION_DIFFUSION: e = make_engine_advdiff(d, err); break;
     case CMDG_PHYSICS_DRY_ATMOS: e = make_engine_atmos(d, err); break;
     case CMDG_PHYSICS_HYDROSTATIC_BOUSSINESQ: e = make_engine_ocean(d, err); break;
+    case CMDG_PHYSICS_PRESSURE_GRADIENT: e = make_engine_pgrad(d, err); break;
     default: err = "unknown physics_id"; break;
     }
     if (!e) {
@@ -1047,6 +1049,18 @@ int cmdg_group_rhs(cmdg_handle *handles, int32_t n, double **tendency, double **
     if (r)
         for (int i = 0; i < n; ++i) set_err(handles[i], r);
     return r;
+}
+
+int cmdg_group_halo(cmdg_handle *handles, int32_t n, double **arrays, int32_t nstate)
+{
+    if (!handles || n < 1 || !arrays) return CMDG_ERR_INVALID;
+    for (int i = 0; i < n; ++i)
+        if (int r = handles[i]->eng->halo_begin(SLOT_Q, arrays[i], nstate)) return set_err(handles[i], r);
+    for (int i = 0; i < n; ++i)
+        if (int r = handles[i]->eng->halo_end(SLOT_Q, arrays[i], nstate)) return set_err(handles[i], r);
+    for (int i = 0; i < n; ++i)
+        if (int r = handles[i]->eng->synchronize()) return set_err(handles[i], r);
+    return CMDG_OK;
 }
 
 int cmdg_group_lsrk_run(cmdg_handle *handles, int32_t n, double **Q, double **dQ, double t,

@@ -286,5 +286,7 @@ EngineBase *make_engine_atmos(const cmdg_desc *d, std::string &err);
 int counts_atmos(const int32_t *iparam, int32_t out[6]);
 EngineBase *make_engine_ocean(const cmdg_desc *d, std::string &err);
 int counts_ocean(const int32_t *iparam, int32_t out[6]);
+EngineBase *make_engine_pgrad(const cmdg_desc *d, std::string &err);
+int counts_pgrad(const int32_t *iparam, int32_t out[6]);
 
 }  // namespace cmdg

@@ -1,6 +1,8 @@
-// Engine instantiations for the hydrostatic Boussinesq ocean law (physics_ocean.h).
+// Engine instantiations for the hydrostatic Boussinesq ocean law (physics_ocean.h) and the
+// PressureGradientModel used by the reference-state initialisation (physics_pgrad.h).
 #include "engine.h"
 #include "physics_ocean.h"
+#include "physics_pgrad.h"
 
 namespace cmdg {
 
@@ -24,6 +26,30 @@ EngineBase *make_engine_ocean(const cmdg_desc *d, std::string &err)
     case 5: return make_engine<HydroBoussinesq, 6>(d);
     default:
         err = "HydrostaticBoussinesq: polynomial order not compiled in (have N = 2..5)";
+        return nullptr;
+    }
+}
+
+int counts_pgrad(const int32_t *, int32_t out[6])
+{
+    out[0] = 3;
+    out[1] = 1;
+    out[2] = out[3] = out[4] = out[5] = 0;
+    return CMDG_OK;
+}
+
+EngineBase *make_engine_pgrad(const cmdg_desc *d, std::string &err)
+{
+    switch (d->N[0]) {
+    case 1: return make_engine<PressureGradient, 2>(d);
+    case 2: return make_engine<PressureGradient, 3>(d);
+    case 3: return make_engine<PressureGradient, 4>(d);
+    case 4: return make_engine<PressureGradient, 5>(d);
+    case 5: return make_engine<PressureGradient, 6>(d);
+    case 6: return make_engine<PressureGradient, 7>(d);
+    case 7: return make_engine<PressureGradient, 8>(d);
+    default:
+        err = "PressureGradientModel: polynomial order not compiled in (have N = 1..7)";
         return nullptr;
     }
 }

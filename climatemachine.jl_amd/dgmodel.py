@@ -19,7 +19,8 @@ import torch
 from . import _lib
 from .balancelaws import EveryDirection, RusanovNumericalFlux
 
-__all__ = ["DGModel", "connect_local", "group_rhs", "group_lsrk_run", "rccl_unique_id",
+__all__ = ["DGModel", "connect_local", "group_rhs", "group_lsrk_run", "group_halo",
+           "reference_pressure_gradient", "rccl_unique_id",
            "ADVECTIVE_COURANT", "NONDIFFUSIVE_COURANT", "DIFFUSIVE_COURANT"]
 
 ADVECTIVE_COURANT, NONDIFFUSIVE_COURANT, DIFFUSIVE_COURANT = 0, 1, 2
@@ -74,6 +75,10 @@ class DGModel:
         self._nsend = np.asarray(g.nabrtovmapsend, dtype=np.int64).reshape(-1)
         self._nrecv = np.asarray(g.nabrtovmaprecv, dtype=np.int64).reshape(-1)
         aux = law.init_state_auxiliary(g) if state_auxiliary is None else state_auxiliary
+        if state_auxiliary is None and getattr(law, "discrete_hydrostatic_balance", False):
+            # atmos_init_aux!(::HydrostaticState) step 2 (ref_state.jl:150-175) on the device
+            gradp = reference_pressure_gradient(g, aux[:, law.off_ref + 1, :], device)
+            law.rebalance_reference_state(g, aux, gradp)
         self.state_auxiliary = _dev(aux, dev) if isinstance(aux, np.ndarray) else aux
         ne, Np = g.nelem, g.Np
         self.state_gradient_flux = torch.zeros((ne, max(law.ngradflux, 1), Np), dtype=torch.float64, device=dev)
@@ -317,6 +322,34 @@ class DGModel:
                                            C.cast(C.byref(ms), C.c_void_p),
                                            C.cast(C.byref(n), C.c_void_p)), self.handle)
         return ms.value, n.value
+
+
+def reference_pressure_gradient(grid, p, device="cuda:0"):
+    """``grad reference_pressure`` (src/Atmos/Model/ref_state.jl:235-262): one evaluation of
+    the PressureGradientModel operator with central fluxes; ``(nelem, 3, Np)`` numpy array.
+    Ghost elements hold the analytic pressure already, so this evaluation needs no exchange:
+    the operator is built on a view of the grid without neighbours."""
+    import copy
+    from .balancelaws import PressureGradientModel
+    g = copy.copy(grid)
+    g.nabrtorank = []
+    g.nabrtovmapsend = np.zeros((2, 0), dtype=np.int64)
+    g.nabrtovmaprecv = np.zeros((2, 0), dtype=np.int64)
+    dg = DGModel(PressureGradientModel(p), g, numerical_flux_first_order=1, device=device)
+    Q = dg.create_state(3)
+    T = dg.create_state(3)
+    dg(T, Q, 0.0, 1.0, 0.0)
+    out = T.cpu().numpy()
+    dg.close()
+    return out
+
+
+def group_halo(dgs, arrays):
+    """One ghost exchange of a state-like array per connected handle (``cmdg_group_halo``)."""
+    for d in dgs:
+        d._torch_ready()
+    _lib.check(dgs[0].L.cmdg_group_halo(_harr(dgs), len(dgs), _parr(arrays), arrays[0].shape[1]),
+               dgs[0].handle)
 
 
 def rccl_unique_id():

@@ -42,7 +42,8 @@ enum { CMDG_RUSANOV = 0, CMDG_CENTRAL_FIRST_ORDER = 1 };
 /* balance laws carried as device functors (pointwise Julia physics cannot cross a C ABI) */
 enum {
     CMDG_PHYSICS_ADVECTION_DIFFUSION = 1, CMDG_PHYSICS_DRY_ATMOS = 2,
-    CMDG_PHYSICS_HYDROSTATIC_BOUSSINESQ = 3
+    CMDG_PHYSICS_HYDROSTATIC_BOUSSINESQ = 3,
+    CMDG_PHYSICS_PRESSURE_GRADIENT = 4 /* PressureGradientModel, ref_state.jl:196-233 */
 };
 
 /* Construction record: the fields of `DGModel(balance_law, grid, nf1, nf2, nfgrad;
@@ -144,6 +145,10 @@ int cmdg_comm_connect_local(cmdg_handle *handles, int32_t n);
  * plays every rank): arrays of n per-rank pointers. */
 int cmdg_group_rhs(cmdg_handle *handles, int32_t n, double **tendency, double **Q, double t,
                    double alpha, double beta);
+/* one ghost exchange of a state-like array per handle (begin on all, then end on all):
+ * e.g. state_auxiliary columns after initialisation (SpaceDiscretization.jl create_state +
+ * MPIStateArrays.begin/end_ghost_exchange!) */
+int cmdg_group_halo(cmdg_handle *handles, int32_t n, double **arrays, int32_t nstate);
 int cmdg_group_lsrk_run(cmdg_handle *handles, int32_t n, double **Q, double **dQ, double t,
                         double dt, int64_t nsteps, int32_t nstages, const double *rka,
                         const double *rkb, const double *rkc);

@@ -63,6 +63,8 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.orc_advdiff_new.restype = C.POINTER(_Physics)
         _LIB.orc_advdiff_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _LIB.orc_pgrad_new.restype = C.POINTER(_Physics)
+        _LIB.orc_pgrad_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         if hasattr(_LIB, "orc_ocean_new"):
             _LIB.orc_ocean_new.restype = C.POINTER(_Physics)
             _LIB.orc_ocean_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -119,7 +121,8 @@ class OraclePhysics:
         ip, dp = law.descriptor()
         self._ip = np.ascontiguousarray(ip, dtype=np.int32)
         self._dp = np.ascontiguousarray(dp, dtype=np.float64)
-        ctor = {1: "orc_advdiff_new", 2: "orc_atmos_new", 3: "orc_ocean_new"}[law.physics_id]
+        ctor = {1: "orc_advdiff_new", 2: "orc_atmos_new", 3: "orc_ocean_new",
+                4: "orc_pgrad_new"}[law.physics_id]
         self.c = getattr(lib(), ctor)(_p(self._ip), _p(self._dp), int(nf_first))
         ph = self.c.contents
         self.ns, self.naux, self.ngrad = ph.ns, ph.naux, ph.ngrad
@@ -159,6 +162,10 @@ class OracleDGModel:
         ne, Np = grid.nelem, grid.Np
         self.state_auxiliary = (law.init_state_auxiliary(grid) if state_auxiliary is None
                                 else state_auxiliary)
+        if state_auxiliary is None and getattr(law, "discrete_hydrostatic_balance", False):
+            # atmos_init_aux!(::HydrostaticState) step 2 (ref_state.jl:150-175)
+            gradp = reference_pressure_gradient(grid, self.state_auxiliary[:, law.off_ref + 1, :])
+            law.rebalance_reference_state(grid, self.state_auxiliary, gradp)
         self.state_gradient_flux = np.zeros((ne, max(self.ph.ngf, 0), Np))
         self.Qhypervisc_grad = np.zeros((ne, 3 * self.ph.ngl, Np))
         self.Qhypervisc_div = np.zeros((ne, self.ph.nhyp, Np))
@@ -335,6 +342,25 @@ class OracleDGModel:
         self.launch_interface_tendency(tendency, Q, t, alpha, "exterior")
         if self.tendency_filter is not None:          # DGModel.jl:417-425
             apply_filter(tendency, self.tendency_filter[1], self.grid, self.tendency_filter[0])
+
+
+def reference_pressure_gradient(grid, p):
+    """``grad reference_pressure`` (ref_state.jl:235-262): the tendency of the
+    PressureGradientModel on ``grid`` with central fluxes, ``(nelem, 3, Np)``; the ghost
+    elements carry the analytic pressure, so no exchange is needed."""
+    from types import SimpleNamespace
+    law = SimpleNamespace(physics_id=4, ns=3, naux=1, ngrad=0, ngradflux=0, ngradlap=0, nhyper=0,
+                          descriptor=lambda: (np.zeros(16, dtype=np.int32), np.zeros(32)))
+    aux = np.ascontiguousarray(p[:, None, :], dtype=np.float64)
+    dg = OracleDGModel(law, grid, nf_first=1, state_auxiliary=aux)
+    Q = np.zeros((grid.nelem, 3, grid.Np))
+    T = np.zeros_like(Q)
+    comm = dg.exchange
+    dg.exchange = type("NoComm", (), {"begin": lambda s, a, n: None,
+                                      "end": lambda s, a, n, t: None})()
+    dg(T, Q, 0.0, 1.0, 0.0)
+    dg.exchange = comm
+    return T
 
 
 # ---- LSRK54 Carpenter-Kennedy (LowStorageRungeKuttaMethod.jl:293-327) -------------
