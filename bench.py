@@ -264,6 +264,20 @@ def main():
         elems_per_launch = grid.nreal * 5 * args.steps / nl   # interior/exterior launches split
         bytes_per_launch = algorithmic_bytes_per_node(law, dom) * grid.Np * elems_per_launch
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        # HBM-side traffic of the dominant kernel from the committed rocprofv3 --pmc passes of
+        # this same command (scripts/pmc_any.sh; FETCH_SIZE and WRITE_SIZE in separate passes, KB
+        # units, FETCH_SIZE doubled as the gfx950 guide prescribes and as
+        # profiles/r01_pmc_calibration_n30.json confirms for this library's 8-byte-per-lane
+        # loads); only quoted for the configuration it was measured on
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                "r01_heldsuarez_n11_pmc_hbm_per_launch.json")
+        if (args.workload == "heldsuarez" and world == 1 and grid.nreal == 5808
+                and not args.filter and os.path.exists(pmc_file)):
+            pm = json.load(open(pmc_file)).get("k_%s" % dom.lower())
+            if pm and "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+                traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"])
+                traffic_src = "profiles/r01_heldsuarez_n11_pmc_hbm_per_launch.json"
         out = {
             "metric": "DG RHS DOF-updates/sec", "value": dofs / el, "unit": "DOF-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -275,7 +289,8 @@ def main():
             "kernels_ms": {k: {"avg_ms": v[0], "launches": v[1]} for k, v in kern.items()},
             "roofline": {"bound": "hbm", "kernel": "k_%s" % dom.lower(), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
                          "algorithmic_bytes_per_node": algorithmic_bytes_per_node(law, dom),
                          "avg_launch_ms": avg_ms,
                          "timing": "HIP events on the launch stream, second pass of the same "
