@@ -107,6 +107,32 @@ class SolidBodyRotation:
     u_scale = 2 * np.pi
 
 
+class ReversingDeformationalFlow:
+    """``ReversingDeformationalFlow`` (advection_sphere.jl:56-103, after Lauritzen et al. 2012):
+    two Gaussian hills in a time-dependent deformational flow that reverses at t = 2.5 and
+    returns them at t = 5.  The velocity lives in the auxiliary state and is refreshed by the
+    nodal ``update_auxiliary_state!`` at every right-hand-side evaluation (on the device:
+    ``AdvDiff::update_aux``, problem 7)."""
+    problem_id = 7
+    finaltime = 5.0
+    u_scale = 2.9
+
+    def dparam(self):
+        return np.zeros(32)
+
+    def init_velocity_diffusion(self, law, aux, coord):
+        pass                                   # init_velocity_diffusion!(...) = nothing
+
+    def initial_condition(self, coord, t):
+        x, y, z = coord
+        r = np.sqrt(x * x + y * y + z * z)
+        rho = 0.0 * x
+        for lam, phi in ((5 * np.pi / 6, 0.0), (7 * np.pi / 6, 0.0)):
+            xi, yi, zi = r * np.cos(phi) * np.cos(lam), r * np.cos(phi) * np.sin(lam), r * np.sin(phi)
+            rho = rho + 0.95 * np.exp(-5 * ((x - xi) ** 2 + (y - yi) ** 2 + (z - zi) ** 2))
+        return rho
+
+
 class DiffusionSphere:
     """``DiffusionSphere`` of test/Numerics/DGMethods/advection_diffusion/
     diffusion_hyperdiffusion_sphere.jl:25-55.  The reference runs it as a two-equation law

@@ -225,7 +225,7 @@ struct EngineT : EngineBase {
     void launch_update_aux(const RhsCtx &c, int64_t e0, int64_t e1) override
     {
         if constexpr (P::HAS_UPDATE_AUX) {
-            if (e1 <= e0) return;
+            if (e1 <= e0 || !P::update_aux_active(prm)) return;
             const int64_t n = (e1 - e0) * KDims<NQ_>::Np;
             prof_begin(CMDG_K_UPDATE_AUX, s_comp);
             hipLaunchKernelGGL((k_update_aux<P, NQ_>), dim3((unsigned)((n + 255) / 256)), dim3(256),
@@ -247,7 +247,7 @@ struct EngineT : EngineBase {
                                g.vgeo, g.nvgeo, Q, aux, gf, kind, dt, t, dir, out_elem);
         return CMDG_OK;
     }
-    bool has_update_aux() const override { return P::HAS_UPDATE_AUX; }
+    bool has_update_aux() const override { return P::HAS_UPDATE_AUX && P::update_aux_active(prm); }
     bool fused_update_aux() const override { return P::HAS_UPDATE_AUX && P::FUSE_UPDATE_AUX; }
     int init_derived() override
     {

@@ -33,7 +33,9 @@ struct AdvDiff {
     static constexpr int NGL = HYPER ? 1 : 0;
     static constexpr int NHYP = HYPER ? 3 : 0;
     static constexpr int OU = 3, OD = 3 + (ADV ? 3 : 0), OH = OD + (DIFF ? 9 : 0);
-    static constexpr bool HAS_UPDATE_AUX = false;
+    // only problems with variable coefficients refresh the auxiliary state (problem 7:
+    // ReversingDeformationalFlow, advection_sphere.jl:56-103); see update_aux_active
+    static constexpr bool HAS_UPDATE_AUX = ADV;
     static constexpr bool FUSE_UPDATE_AUX = false;
     static constexpr int NUPD = 0;
     __host__ __device__ static constexpr int upd_aux(int) { return 0; }
@@ -245,7 +247,26 @@ struct AdvDiff {
             if (bc & BC_ANY(2)) lapP[0] = 0.0;
         }
     }
-    __device__ static void update_aux(const Params &, const double *, double *, double) {}
+    __host__ __device__ static bool update_aux_active(const Params &m) { return ADV && m.problem == 7; }
+    // update_velocity_diffusion!(::ReversingDeformationalFlow, ...)  advection_sphere.jl:76-101
+    __device__ static void update_aux(const Params &m, const double *, double *aux, double t)
+    {
+        if constexpr (ADV) {
+            if (m.problem != 7) return;
+            const double x = aux[0], y = aux[1], z = aux[2];
+            const double r = sqrt(x * x + y * y + z * z);
+            const double lam = atan2(y, x), phi = asin(z / r);
+            const double T = 5.0;
+            const double lamp = lam - 2 * M_PI * t / T;
+            const double sl = sin(lamp);
+            const double ul = 10 * r / T * (sl * sl) * sin(2 * phi) * cos(M_PI * t / T) +
+                              2 * M_PI * r / T * cos(phi);
+            const double up = 10 * r / T * sin(2 * lamp) * cos(phi) * cos(M_PI * t / T);
+            aux[OU + 0] = -ul * sin(lam) - up * cos(lam) * sin(phi);
+            aux[OU + 1] = +ul * cos(lam) - up * sin(lam) * sin(phi);
+            aux[OU + 2] = +up * cos(phi);
+        }
+    }
     // the test law defines no local_courant function
     static constexpr bool HAS_COURANT = false;
     static constexpr bool HAS_PENALTY = false;  // update_penalty! is the default no-op

@@ -46,6 +46,7 @@ struct DryAtmos {
     static constexpr int NGL = HYPER ? 4 : 0;
     static constexpr int NHYP = HYPER ? 12 : 0;
     static constexpr bool HAS_UPDATE_AUX = true;
+    __host__ __device__ static bool update_aux_active(const Params &) { return true; }
     // the refresh only writes moisture.theta_v / air_T, which no dry tendency reads, so it
     // can ride in the gradient kernel's first phase instead of costing a pass of its own
     static constexpr bool FUSE_UPDATE_AUX = true;

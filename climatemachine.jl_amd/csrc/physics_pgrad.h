@@ -86,6 +86,7 @@ struct PressureGradient {
     {
     }
     __device__ static void update_aux(const Params &, const double *, double *, double) {}
+    __host__ __device__ static bool update_aux_active(const Params &) { return false; }
     __device__ static double courant(const Params &, int, const double *, const double *,
                                      const double *, double, double, double, int)
     {

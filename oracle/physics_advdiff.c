@@ -244,6 +244,25 @@ static void ad_bhigher(const void *p, int bctag, double *QP, double *auxP, doubl
         lapP[0] = 0.0;
 }
 
+/* update_velocity_diffusion!(::ReversingDeformationalFlow, ...)  advection_sphere.jl:76-101 */
+static void ad_update_aux(const void *p, const double *Q, double *aux, double t)
+{
+    const advdiff_t *m = (const advdiff_t *)p;
+    (void)Q;
+    const double x = aux[0], y = aux[1], z = aux[2];
+    const double r = sqrt(x * x + y * y + z * z);
+    const double lam = atan2(y, x), phi = asin(z / r);
+    const double T = 5.0;
+    const double lamp = lam - 2 * M_PI * t / T;
+    const double sl = sin(lamp);
+    const double ul = 10 * r / T * (sl * sl) * sin(2 * phi) * cos(M_PI * t / T) +
+                      2 * M_PI * r / T * cos(phi);
+    const double up = 10 * r / T * sin(2 * lamp) * cos(phi) * cos(M_PI * t / T);
+    aux[m->ou + 0] = -ul * sin(lam) - up * cos(lam) * sin(phi);
+    aux[m->ou + 1] = +ul * cos(lam) - up * sin(lam) * sin(phi);
+    aux[m->ou + 2] = +up * cos(phi);
+}
+
 orc_physics *orc_advdiff_new(const int *iparam, const double *dparam, int nf_first)
 {
     orc_physics *ph = (orc_physics *)calloc(1, sizeof(orc_physics));
@@ -283,7 +302,7 @@ orc_physics *orc_advdiff_new(const int *iparam, const double *dparam, int nf_fir
     ph->boundary_flux_second_order = ad_bflux2;
     ph->boundary_state_divergence = ad_bdiv;
     ph->boundary_state_higher_order = ad_bhigher;
-    ph->update_aux = NULL;
+    ph->update_aux = (m->adv && m->problem == 7) ? ad_update_aux : NULL;
     return ph;
 }
 

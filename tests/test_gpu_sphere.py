@@ -20,16 +20,17 @@ def torch():
 
 
 @pytest.mark.parametrize("level", [1, 2, 3, 4])
-def test_solid_body_rotation_on_the_gpu(cm, torch, level):
-    law, grid, dt = advection_sphere_setup(level)
+@pytest.mark.parametrize("problem", ["SolidBodyRotation", "ReversingDeformationalFlow"])
+def test_sphere_advection_on_the_gpu(cm, torch, problem, level):
+    law, grid, dt = advection_sphere_setup(level, problem=problem)
     dg = cm.dgmodel.DGModel(law, grid)
     Q = dg.init_ode_state(0.0)
     Qe = Q.clone()
     solver = cm.odesolvers.LSRK144NiegemannDiehlBusch(dg, Q, dt=dt)
-    cm.odesolvers.solve(Q, solver, timeend=1.0)
+    cm.odesolvers.solve(Q, solver, timeend=law.problem.finaltime)
     err = dg.euclidean_distance(Q, Qe)
     g = GOLD["advection_sphere"]
-    exp = g["SolidBodyRotation_LSRK144"][level - 1]
+    exp = g[problem + "_LSRK144"][level - 1]
     assert abs(err - exp) <= g["rtol"] * exp, (err, exp)
     assert abs(err - exp) <= 1e-9 * exp
     dg.close()

@@ -16,20 +16,24 @@ RKA, RKB, RKC = cm.odesolvers.LSRK144_COEFFICIENTS
 
 
 @pytest.mark.parametrize("level", [1, 2, 3])
-def test_solid_body_rotation_matches_reference_error(oracle, level):
-    law, grid, dt = advection_sphere_setup(level)
+@pytest.mark.parametrize("problem", ["SolidBodyRotation", "ReversingDeformationalFlow"])
+def test_sphere_advection_matches_reference_error(oracle, problem, level):
+    """ReversingDeformationalFlow: the velocity is refreshed by the nodal
+    update_auxiliary_state! at every stage time (advection_sphere.jl:76-101)."""
+    law, grid, dt = advection_sphere_setup(level, problem=problem)
+    tend = law.problem.finaltime
     dg = oracle.OracleDGModel(law, grid, nf_first=0)
     Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
     Qe = Q.copy()
     dQ = np.zeros_like(Q)
     t = 0.0
-    while t < 1.0:                       # solve! with adjustfinalstep
-        step = min(dt, 1.0 - t) if t + dt > 1.0 else dt
+    while t < tend:                      # solve! with adjustfinalstep
+        step = tend - t if t + dt > tend else dt
         oracle.lsrk_step(dg, Q, dQ, t, step, RKA, RKB, RKC)
         t += step
     err = np.sqrt(oracle.weighted_norm2_local(grid, Q, Qe))
     g = GOLD["advection_sphere"]
-    exp = g["SolidBodyRotation_LSRK144"][level - 1]
+    exp = g[problem + "_LSRK144"][level - 1]
     assert abs(err - exp) <= g["rtol"] * exp
     assert abs(err - exp) <= 1e-10 * exp          # observed 4e-14 .. 5e-12
     M = grid.vgeo[: grid.nreal, 9, :]
