@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
 // ---------------------------------------------------------------------------------
 // Gradient pass: volume_gradients! (:934-1328) + dgsem_interface_gradients! (:1365-1651)
 template <class P, int NQ>
-__global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_GRAD_MINW) k_gradients(const PassArgs<P> a)
+__global__ void __launch_bounds__(KDims<NQ>::NT, (NQ == 5 ? CMDG_GRAD_MINW : 1)) k_gradients(const PassArgs<P> a)
 {
     using KD = KDims<NQ>;
     constexpr int Np = KD::Np, Nfp = KD::Nfp, NS = P::NS, NAUX = P::NAUX, NGRAD = P::NGRAD,
