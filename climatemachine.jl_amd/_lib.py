@@ -134,6 +134,6 @@ def lib():
 def check(status, handle=None):
     if status != 0:
         L = lib()
-        msg = L.cmdg_last_error(handle).decode() if True else ""
+        msg = L.cmdg_last_error(handle).decode()
         raise CmdgError("libcmdg: %s (%d): %s" % (
             L.cmdg_status_string(status).decode(), status, msg))
