@@ -230,6 +230,32 @@ class ConstantHyperDiffusion:
         return np.sin(kx) * np.exp(-self._c() * t)
 
 
+class HyperDiffusionBC:
+    """``ConstantHyperDiffusion{FT}(mu, k)`` of test/Numerics/DGMethods/advection_diffusion/
+    hyperdiffusion_bc.jl:25-112: ``H = mu I``; the solution ``cos(k1 x) cos(k2 y) cos(k3 z)
+    exp(-|k|^4 mu t)`` supplies boundary data of orders 0-3 (value, gradient, Laplacian,
+    gradient of the Laplacian)."""
+    problem_id = 2
+
+    def __init__(self, mu, k):
+        self.mu, self.k = float(mu), np.asarray(k, dtype=np.float64)
+
+    def dparam(self):
+        d = np.zeros(32)
+        d[0] = self.mu
+        d[1:4] = self.k
+        return d
+
+    def init_velocity_diffusion(self, law, aux, coord):
+        aux[:, law.off_H:law.off_H + 9, :] = (self.mu * np.eye(3)).flatten(order="F")[None, :, None]
+
+    def initial_condition(self, coord, t):
+        k = self.k
+        k2 = float(np.sum(k ** 2))
+        return (np.cos(k[0] * coord[0]) * np.cos(k[1] * coord[1]) * np.cos(k[2] * coord[2])
+                * np.exp(-k2 ** 2 * self.mu * t))
+
+
 class DirectionSplitBox:
     """``TestProblem{adv, diff, dir, Box}`` of the reference's tendency-splitting test
     (direction_splitting_advection_diffusion.jl:28-68): u = P sin(pi x), D = P / 200,

@@ -3,6 +3,8 @@
 // and the problems that supply its coefficients and boundary data:
 //   problem 0  Pseudo1D                 pseudo1D_advection_diffusion.jl:28-68
 //   problem 1  ConstantHyperDiffusion   periodic_3D_hyperdiffusion.jl:29-63
+//   problem 2  ConstantHyperDiffusion{mu, k} with boundary data  hyperdiffusion_bc.jl:25-112
+//   problem 7  ReversingDeformationalFlow (velocity refresh)     advection_sphere.jl:56-103
 //
 // Parameter block (cmdg_desc.iparam / dparam):
 //   iparam[0]=num_equations (1)  [1]=advection [2]=diffusion [3]=hyperdiffusion
@@ -88,8 +90,43 @@ struct AdvDiff {
             double kx = 0;
             for (int i = 0; i < dim; ++i) kx += k[i] * x[i];
             return sin(kx) * exp(-c * t);
+        } else if (m.problem == 2) {  // d[0] = mu, d[1..3] = k
+            const double *k = m.d + 1;
+            return cos(k[0] * x[0]) * cos(k[1] * x[1]) * cos(k[2] * x[2]) * hbc_e(m, t);
         }
         return 0.0;
+    }
+    __device__ static double hbc_e(const Params &m, double t)
+    {
+        const double *k = m.d + 1;
+        const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+        return exp(-(k2 * k2) * m.d[0] * t);
+    }
+    __device__ static void hbc_sincos(const Params &m, const double *x, double *v)
+    {
+        const double *k = m.d + 1;
+        v[0] = k[0] * sin(k[0] * x[0]) * cos(k[1] * x[1]) * cos(k[2] * x[2]);
+        v[1] = k[1] * cos(k[0] * x[0]) * sin(k[1] * x[1]) * cos(k[2] * x[2]);
+        v[2] = k[2] * cos(k[0] * x[0]) * cos(k[1] * x[1]) * sin(k[2] * x[2]);
+    }
+    // inhomogeneous_data!(Val(2)) / Val(3) of hyperdiffusion_bc.jl:80-112
+    __device__ static double problem_lap(const Params &m, const double *x, double t)
+    {
+        if (m.problem != 2) return 0.0;
+        const double *k = m.d + 1;
+        const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+        return -k2 * cos(k[0] * x[0]) * cos(k[1] * x[1]) * cos(k[2] * x[2]) * hbc_e(m, t);
+    }
+    __device__ static void problem_gradlap(const Params &m, double *g, const double *x, double t)
+    {
+        g[0] = g[1] = g[2] = 0.0;
+        if (m.problem != 2) return;
+        const double *k = m.d + 1;
+        const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+        double v[3];
+        hbc_sincos(m, x, v);
+        const double e = hbc_e(m, t);
+        for (int i = 0; i < 3; ++i) g[i] = (k2 * v[i]) * e;
     }
     __device__ static void problem_grad(const Params &m, double *g, const double *x, double t)
     {
@@ -101,6 +138,11 @@ struct AdvDiff {
             for (int i = 0; i < 3; ++i)
                 g[i] = -(2 * n[i] * a / (4 * be * (de + t)) *
                          exp(-(a * a) / (4 * be * (de + t))) / sqrt(1 + t / de));
+        } else if (m.problem == 2) {  // inhomogeneous_data!(Val(1)) hyperdiffusion_bc.jl:63-79
+            double v[3];
+            hbc_sincos(m, x, v);
+            const double e = hbc_e(m, t);
+            for (int i = 0; i < 3; ++i) g[i] = -v[i] * e;
         } else {
             g[0] = g[1] = g[2] = 0.0;
         }
@@ -215,7 +257,10 @@ struct AdvDiff {
                 }
             }
             if constexpr (HYPER) {
-                if (bc & BC_ANY(3)) {
+                if (bc & BC_INHOM(3)) {
+                    problem_gradlap(m, g, auxM, t);
+                    matvec3(hypP, auxM + OH, g);
+                } else if (bc & BC_HOM(3)) {
                     g[0] = g[1] = g[2] = 0.0;
                     matvec3(hypP, auxM + OH, g);
                 }
@@ -239,12 +284,15 @@ struct AdvDiff {
     // boundary_state!(::CentralNumericalFluxHigherOrder, ...) (:593-617)
     __device__ static void boundary_state_higher_order(const Params &m, int bctag, double *,
                                                        double *, double *lapP, const double *,
-                                                       const double *, const double *,
-                                                       const double *, double)
+                                                       const double *, const double *auxM,
+                                                       const double *, double t)
     {
         if constexpr (HYPER) {
             const int bc = m.bc[bctag - 1];
-            if (bc & BC_ANY(2)) lapP[0] = 0.0;
+            if (bc & BC_INHOM(2))
+                lapP[0] = problem_lap(m, auxM, t);
+            else if (bc & BC_HOM(2))
+                lapP[0] = 0.0;
         }
     }
     __host__ __device__ static bool update_aux_active(const Params &m) { return ADV && m.problem == 7; }

@@ -71,18 +71,65 @@ static double chd_rho(const advdiff_t *m, const double *x, double t)
     return sin(kx) * exp(-c * t);
 }
 
+/* ConstantHyperDiffusion{mu, k} of hyperdiffusion_bc.jl:25-112: d[0]=mu, d[1..3]=k */
+static double hbc_e(const advdiff_t *m, double t)
+{
+    const double *k = m->d + 1;
+    const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+    return exp(-(k2 * k2) * m->d[0] * t);
+}
+static double hbc_rho(const advdiff_t *m, const double *x, double t)
+{
+    const double *k = m->d + 1;
+    return cos(k[0] * x[0]) * cos(k[1] * x[1]) * cos(k[2] * x[2]) * hbc_e(m, t);
+}
+static void hbc_sincos(const advdiff_t *m, const double *x, double *v)
+{
+    const double *k = m->d + 1;
+    v[0] = k[0] * sin(k[0] * x[0]) * cos(k[1] * x[1]) * cos(k[2] * x[2]);
+    v[1] = k[1] * cos(k[0] * x[0]) * sin(k[1] * x[1]) * cos(k[2] * x[2]);
+    v[2] = k[2] * cos(k[0] * x[0]) * cos(k[1] * x[1]) * sin(k[2] * x[2]);
+}
+
 static double problem_rho(const advdiff_t *m, const double *x, double t)
 {
     switch (m->problem) {
     case 0: return p1d_rho(m, x, t);
     case 1: return chd_rho(m, x, t);
+    case 2: return hbc_rho(m, x, t);
     default: return 0.0;
     }
+}
+/* inhomogeneous_data!(Val(2), ...) and Val(3) (hyperdiffusion_bc.jl:80-112) */
+static double problem_lap(const advdiff_t *m, const double *x, double t)
+{
+    if (m->problem != 2) return 0.0;
+    const double *k = m->d + 1;
+    const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+    return -k2 * cos(k[0] * x[0]) * cos(k[1] * x[1]) * cos(k[2] * x[2]) * hbc_e(m, t);
+}
+static void problem_gradlap(const advdiff_t *m, double *g, const double *x, double t)
+{
+    g[0] = g[1] = g[2] = 0.0;
+    if (m->problem != 2) return;
+    const double *k = m->d + 1;
+    const double k2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+    double v[3];
+    hbc_sincos(m, x, v);
+    const double e = hbc_e(m, t);
+    for (int i = 0; i < 3; ++i) g[i] = (k2 * v[i]) * e;
 }
 static void problem_grad(const advdiff_t *m, double *g, const double *x, double t)
 {
     switch (m->problem) {
     case 0: p1d_grad(m, g, x, t); break;
+    case 2: { /* inhomogeneous_data!(Val(1), ::ConstantHyperDiffusion, ...)  hyperdiffusion_bc.jl:63-79 */
+        double v[3];
+        hbc_sincos(m, x, v);
+        const double e = hbc_e(m, t);
+        for (int i = 0; i < 3; ++i) g[i] = -v[i] * e;
+        break;
+    }
     default: g[0] = g[1] = g[2] = 0.0;
     }
 }
@@ -207,7 +254,7 @@ static void ad_bflux2(const void *p, int bctag, double *F, double *QP, double *g
     }
     if (m->hyper) {
         if (bc & BC_INHOM(3)) {
-            g[0] = g[1] = g[2] = 0.0; /* problem-specific data: none of the problems in scope */
+            problem_gradlap(m, g, auxM, t);
             matvec3(hypP, auxM + m->oH, g);
         } else if (bc & BC_HOM(3)) {
             g[0] = g[1] = g[2] = 0.0;
@@ -235,11 +282,11 @@ static void ad_bhigher(const void *p, int bctag, double *QP, double *auxP, doubl
                        double t)
 {
     const advdiff_t *m = (const advdiff_t *)p;
-    (void)QP; (void)auxP; (void)n; (void)QM; (void)auxM; (void)lapM; (void)t;
+    (void)QP; (void)auxP; (void)n; (void)QM; (void)lapM;
     if (!m->hyper) return;
     const int bc = m->bc[bctag - 1];
     if (bc & BC_INHOM(2))
-        lapP[0] = 0.0; /* problem-specific data: none of the problems in scope */
+        lapP[0] = problem_lap(m, auxM, t);
     else if (bc & BC_HOM(2))
         lapP[0] = 0.0;
 }

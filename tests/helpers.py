@@ -206,3 +206,24 @@ def diffusion_sphere_setup(level=1, hyper=False, N=3, rank=0, size=1):
     dt = 300 * dx ** 4
     dt = 2.0 / np.ceil(2.0 / dt)
     return law, grid, dt
+
+
+def hyperdiffusion_bc_setup(level=1, N=4, rank=0, size=1):
+    """hyperdiffusion_bc.jl:150-200, 300-345 (dim = 3): brick [2, 9]^3 with 2^(level-1) * 4
+    elements per side, six boundary tags with mixed data of orders 0-3, H = I / 1000,
+    k = (1, 1, 0), central fluxes, LSRK54 with dt = dx^4 / 100 / mu."""
+    Ne = 2 ** (level - 1) * 4
+    x = np.linspace(2.0, 9.0, Ne + 1)
+    topl = M.StackedBrickTopology([x] * 3, periodicity=(False,) * 3,
+                                  boundary=((1, 2), (3, 4), (5, 6)), connectivity="full",
+                                  rank=rank, size=size)
+    grid = M.DiscontinuousSpectralElementGrid(topl, N)
+    I, H = BL.InhomogeneousBC, BL.HomogeneousBC
+    bcs = ((I(0), I(2)), (I(0), I(1)), (I(3), I(1)), (I(3), I(2)), (H(3), H(1)), (H(3), H(1)))
+    mu = 1 / 1000
+    law = BL.AdvectionDiffusion(3, BL.HyperDiffusionBC(mu, (1, 1, 0)), bcs, advection=False,
+                                diffusion=False, hyperdiffusion=True)
+    dx = M.grids.min_node_distance(grid)
+    dt = dx ** 4 / 100 / mu
+    dt = 1.0 / np.ceil(1.0 / dt)
+    return law, grid, dt

@@ -418,3 +418,32 @@ def test_config1_parity_at_4096_elements(cm, oracle, torch):
     dg(Tg, Q, 0.2, 1.0, 0.0)
     assert rel_linf(Tg.cpu().numpy()[:grid.nreal], To[:grid.nreal]) < TOL
     dg.close()
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_hyperdiffusion_with_boundary_data_gpu(cm, oracle, torch, level):
+    """hyperdiffusion_bc.jl (dim = 3) on the device: golden errors of levels 1-3 and, at level
+    1, the three hyperdiffusion passes against the oracle with every boundary branch active."""
+    from helpers import hyperdiffusion_bc_setup
+    law, grid, dt = hyperdiffusion_bc_setup(level)
+    dg = cm.dgmodel.DGModel(law, grid, numerical_flux_first_order=1)
+    if level == 1:
+        odg = oracle.OracleDGModel(law, grid, nf_first=1)
+        Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.3)
+        Q0 = Q0 + 1e-3 * np.random.default_rng(3).standard_normal(Q0.shape)
+        To = np.zeros_like(Q0)
+        odg(To, Q0.copy(), 0.3, 1.0, 0.0)
+        Tg = _gpu(torch, np.zeros_like(Q0))
+        dg(Tg, _gpu(torch, Q0), 0.3, 1.0, 0.0)
+        assert rel_linf(Tg.cpu().numpy(), To) < TOL
+        assert rel_linf(dg.Qhypervisc_div.cpu().numpy(), odg.Qhypervisc_div) < TOL
+        assert rel_linf(dg.Qhypervisc_grad.cpu().numpy(), odg.Qhypervisc_grad) < TOL
+    Q = dg.init_ode_state(0.0)
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+    cm.odesolvers.solve(Q, solver, timeend=1.0)
+    Qe = dg.init_ode_state(1.0)
+    err = dg.euclidean_distance(Q, Qe)
+    g = GOLD["hyperdiffusion_bc"]
+    exp = g["dim3"][level - 1]
+    assert abs(err - exp) <= g["rtol"] * exp, (err, exp)
+    dg.close()

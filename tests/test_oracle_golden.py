@@ -127,3 +127,21 @@ def test_isentropic_vortex_level1(oracle, nf, name):
     g = GOLD["isentropicvortex"]
     exp = g["dim3"][name][0]
     assert abs(err - exp) <= g["rtol"] * exp, (err, exp)
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_hyperdiffusion_with_boundary_data(oracle, level):
+    """hyperdiffusion_bc.jl (dim = 3): boundary data of orders 0-3 on six differently tagged
+    faces; pins the boundary branches of the divergence, higher-order and second-order
+    numerical fluxes."""
+    from helpers import hyperdiffusion_bc_setup
+    law, grid, dt = hyperdiffusion_bc_setup(level)
+    dg = oracle.OracleDGModel(law, grid, nf_first=1)
+    Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
+    oracle.solve(dg, Q, dt, 1.0)
+    Qe = law.init_state_prognostic(grid, dg.state_auxiliary, 1.0)
+    err = np.sqrt(oracle.weighted_norm2_local(grid, Q, Qe))
+    g = GOLD["hyperdiffusion_bc"]
+    exp = g["dim3"][level - 1]
+    assert abs(err - exp) <= g["rtol"] * exp
+    assert abs(err - exp) <= 1e-10 * exp          # observed 3e-14 / 4e-12
