@@ -256,6 +256,32 @@ class HyperDiffusionBC:
                 * np.exp(-k2 ** 2 * self.mu * t))
 
 
+class HeatEqn:
+    """``HeatEqn{n, kappa, A}`` (pseudo1D_heat_eqn.jl:28-88): ``D = n n'``, solution
+    ``xi + A cos(kappa xi) exp(-kappa^2 t)`` with ``xi = n . x``; used with ``flux_bc=True``
+    (the test's own ``normal_boundary_flux_second_order!`` is the flux form of the Dirichlet /
+    Neumann conditions)."""
+    problem_id = 3
+
+    def __init__(self, n, kappa=10 * np.pi / 2, A=1.0):
+        self.n, self.kappa, self.A = np.asarray(n, dtype=np.float64), float(kappa), float(A)
+
+    def dparam(self):
+        d = np.zeros(32)
+        d[0:3] = self.n
+        d[3], d[4] = self.kappa, self.A
+        return d
+
+    def init_velocity_diffusion(self, law, aux, coord):
+        D = self.n[:, None] * self.n[None, :]
+        aux[:, law.off_D:law.off_D + 9, :] = D.flatten(order="F")[None, :, None]
+
+    def initial_condition(self, coord, t):
+        n = self.n
+        xn = n[0] * coord[0] + n[1] * coord[1] + n[2] * coord[2]
+        return xn + self.A * np.cos(self.kappa * xn) * np.exp(-self.kappa ** 2 * t)
+
+
 class DirectionSplitBox:
     """``TestProblem{adv, diff, dir, Box}`` of the reference's tendency-splitting test
     (direction_splitting_advection_diffusion.jl:28-68): u = P sin(pi x), D = P / 200,

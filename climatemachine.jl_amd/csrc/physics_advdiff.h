@@ -4,6 +4,7 @@
 //   problem 0  Pseudo1D                 pseudo1D_advection_diffusion.jl:28-68
 //   problem 1  ConstantHyperDiffusion   periodic_3D_hyperdiffusion.jl:29-63
 //   problem 2  ConstantHyperDiffusion{mu, k} with boundary data  hyperdiffusion_bc.jl:25-112
+//   problem 3  HeatEqn{n, kappa, A}                              pseudo1D_heat_eqn.jl:28-88
 //   problem 7  ReversingDeformationalFlow (velocity refresh)     advection_sphere.jl:56-103
 //
 // Parameter block (cmdg_desc.iparam / dparam):
@@ -93,6 +94,10 @@ struct AdvDiff {
         } else if (m.problem == 2) {  // d[0] = mu, d[1..3] = k
             const double *k = m.d + 1;
             return cos(k[0] * x[0]) * cos(k[1] * x[1]) * cos(k[2] * x[2]) * hbc_e(m, t);
+        } else if (m.problem == 3) {  // d[0..2] = n, d[3] = kappa, d[4] = A
+            const double *n = m.d, ka = m.d[3], A = m.d[4];
+            const double xn = n[0] * x[0] + n[1] * x[1] + n[2] * x[2];
+            return xn + A * cos(ka * xn) * exp(-(ka * ka) * t);
         }
         return 0.0;
     }
@@ -138,6 +143,11 @@ struct AdvDiff {
             for (int i = 0; i < 3; ++i)
                 g[i] = -(2 * n[i] * a / (4 * be * (de + t)) *
                          exp(-(a * a) / (4 * be * (de + t))) / sqrt(1 + t / de));
+        } else if (m.problem == 3) {  // exact gradient, pseudo1D_heat_eqn.jl:79-88
+            const double *n = m.d, ka = m.d[3], A = m.d[4];
+            const double xn = n[0] * x[0] + n[1] * x[1] + n[2] * x[2];
+            for (int i = 0; i < 3; ++i)
+                g[i] = n[i] * (1 - A * ka * sin(ka * xn) * exp(-(ka * ka) * t));
         } else if (m.problem == 2) {  // inhomogeneous_data!(Val(1)) hyperdiffusion_bc.jl:63-79
             double v[3];
             hbc_sincos(m, x, v);

@@ -91,9 +91,24 @@ static void hbc_sincos(const advdiff_t *m, const double *x, double *v)
     v[2] = k[2] * cos(k[0] * x[0]) * cos(k[1] * x[1]) * sin(k[2] * x[2]);
 }
 
+/* HeatEqn{n, kappa, A} of pseudo1D_heat_eqn.jl:28-53: d[0..2]=n, d[3]=kappa, d[4]=A */
+static double heat_rho(const advdiff_t *m, const double *x, double t)
+{
+    const double *n = m->d, ka = m->d[3], A = m->d[4];
+    const double xn = n[0] * x[0] + n[1] * x[1] + n[2] * x[2];
+    return xn + A * cos(ka * xn) * exp(-(ka * ka) * t);
+}
+static void heat_grad(const advdiff_t *m, double *g, const double *x, double t)
+{ /* the exact gradient of normal_boundary_flux_second_order! (:79-88) */
+    const double *n = m->d, ka = m->d[3], A = m->d[4];
+    const double xn = n[0] * x[0] + n[1] * x[1] + n[2] * x[2];
+    for (int i = 0; i < 3; ++i) g[i] = n[i] * (1 - A * ka * sin(ka * xn) * exp(-(ka * ka) * t));
+}
+
 static double problem_rho(const advdiff_t *m, const double *x, double t)
 {
     switch (m->problem) {
+    case 3: return heat_rho(m, x, t);
     case 0: return p1d_rho(m, x, t);
     case 1: return chd_rho(m, x, t);
     case 2: return hbc_rho(m, x, t);
@@ -123,6 +138,7 @@ static void problem_grad(const advdiff_t *m, double *g, const double *x, double 
 {
     switch (m->problem) {
     case 0: p1d_grad(m, g, x, t); break;
+    case 3: heat_grad(m, g, x, t); break;
     case 2: { /* inhomogeneous_data!(Val(1), ::ConstantHyperDiffusion, ...)  hyperdiffusion_bc.jl:63-79 */
         double v[3];
         hbc_sincos(m, x, v);

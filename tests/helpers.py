@@ -227,3 +227,21 @@ def hyperdiffusion_bc_setup(level=1, N=4, rank=0, size=1):
     dt = dx ** 4 / 100 / mu
     dt = 1.0 / np.ceil(1.0 / dt)
     return law, grid, dt
+
+
+def heat_eqn_setup(level=1, direction=0, N=4, rank=0, size=1):
+    """pseudo1D_heat_eqn.jl:100-150, 225-290 (dim = 3): unit cube with 2^(level-1) * 4 elements
+    per side, tags (1, 2) in every direction = (Neumann data, Dirichlet data) in flux form,
+    D = n n' with n along the operator's direction, LSRK144, dt = 1 / (Ne N^2)^2, t_end = 0.01."""
+    n = {0: np.ones(3) / np.sqrt(3), 1: np.array([1, 1, 0]) / np.sqrt(2),
+         2: np.array([0, 0, 1.0])}[direction]
+    Ne = 2 ** (level - 1) * 4
+    x = np.linspace(0.0, 1.0, Ne + 1)
+    topl = M.StackedBrickTopology([x] * 3, periodicity=(False,) * 3, boundary=((1, 2),) * 3,
+                                  connectivity="full", rank=rank, size=size)
+    grid = M.DiscontinuousSpectralElementGrid(topl, N)
+    law = BL.AdvectionDiffusion(3, BL.HeatEqn(n), (BL.InhomogeneousBC(1), BL.InhomogeneousBC(0)),
+                                flux_bc=True, advection=False)
+    dt = 1 / (Ne * N ** 2) ** 2
+    nsteps = int(np.ceil(0.01 / dt))
+    return law, grid, 0.01 / nsteps, nsteps

@@ -447,3 +447,23 @@ def test_hyperdiffusion_with_boundary_data_gpu(cm, oracle, torch, level):
     exp = g["dim3"][level - 1]
     assert abs(err - exp) <= g["rtol"] * exp, (err, exp)
     dg.close()
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("direction", [0, 1, 2])
+def test_heat_equation_gpu(cm, torch, direction, level):
+    """pseudo1D_heat_eqn.jl (dim = 3) on the device, levels 1-3, three operator directions."""
+    from helpers import heat_eqn_setup
+    law, grid, dt, nsteps = heat_eqn_setup(level, direction)
+    dg = cm.dgmodel.DGModel(law, grid, direction=direction)
+    Q = dg.init_ode_state(0.0)
+    solver = cm.odesolvers.LSRK144NiegemannDiehlBusch(dg, Q, dt=dt)
+    solver.dostep(Q, nsteps=nsteps)
+    dg.synchronize()
+    Qe = dg.init_ode_state(0.01)
+    err = dg.euclidean_distance(Q, Qe)
+    g = GOLD["pseudo1D_heat_eqn"]
+    exp = g["dim3"][DIRS[direction]][level - 1]
+    assert abs(err - exp) <= g["rtol"] * exp or err < exp, (err, exp)     # the test's criterion
+    assert abs(err - exp) <= 1e-6 * exp
+    dg.close()

@@ -145,3 +145,25 @@ def test_hyperdiffusion_with_boundary_data(oracle, level):
     exp = g["dim3"][level - 1]
     assert abs(err - exp) <= g["rtol"] * exp
     assert abs(err - exp) <= 1e-10 * exp          # observed 3e-14 / 4e-12
+
+
+@pytest.mark.parametrize("direction", [0, 1, 2])
+def test_heat_equation_flux_boundary_conditions(oracle, direction):
+    """pseudo1D_heat_eqn.jl (dim = 3, level 1): Dirichlet and Neumann data in flux form
+    (``flux_bc``), operator directions every / horizontal / vertical, LSRK144."""
+    from cmdg_loader import cm
+    from helpers import heat_eqn_setup
+    RKA, RKB, RKC = cm.odesolvers.LSRK144_COEFFICIENTS
+    law, grid, dt, nsteps = heat_eqn_setup(1, direction)
+    dg = oracle.OracleDGModel(law, grid, nf_first=0, direction=direction)
+    Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
+    dQ = np.zeros_like(Q)
+    t = 0.0
+    for _ in range(nsteps):
+        oracle.lsrk_step(dg, Q, dQ, t, dt, RKA, RKB, RKC)
+        t += dt
+    Qe = law.init_state_prognostic(grid, dg.state_auxiliary, 0.01)
+    err = np.sqrt(oracle.weighted_norm2_local(grid, Q, Qe))
+    g = GOLD["pseudo1D_heat_eqn"]
+    exp = g["dim3"][DIRS[direction]][0]
+    assert abs(err - exp) <= 1e-10 * exp          # observed 1e-14 .. 3e-13
