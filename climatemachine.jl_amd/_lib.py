@@ -61,6 +61,18 @@ class CmdgRhsHooks(C.Structure):
         ("nsurf", C.c_int32),
         ("surf_src_col", C.c_int32 * MAX_HOOK_OPS), ("surf_dst_col", C.c_int32 * MAX_HOOK_OPS),
         ("nvertelem", C.c_int32), ("Imat", C.c_void_p),
+        ("has_flow_deviation", C.c_int32), ("flow_u_col", C.c_int32), ("flow_ud_col", C.c_int32),
+        ("flow_H", C.c_double),
+    ]
+
+
+class CmdgOceanCouplingDesc(C.Structure):
+    """``cmdg_ocean_coupling_desc`` of include/cmdg.h."""
+    _fields_ = [
+        ("nvertelem", C.c_int32), ("H", C.c_double), ("Imat", C.c_void_p),
+        ("slow_u_col", C.c_int32), ("slow_eta_col", C.c_int32), ("slow_dGu_col", C.c_int32),
+        ("fast_eta_col", C.c_int32), ("fast_U_col", C.c_int32),
+        ("fast_GU_col", C.c_int32), ("fast_du_col", C.c_int32),
     ]
 
 
@@ -98,6 +110,12 @@ SYMBOLS = [
     ("cmdg_filter_apply", C.c_int, [_vp, _vp, _vp, _i32]),
     ("cmdg_set_filters", C.c_int, [_vp, _vp, _vp, _vp]),
     ("cmdg_set_rhs_hooks", C.c_int, [_vp, _vp]),
+    ("cmdg_ocean_initialize_states", C.c_int, [_vp, _vp, _vp]),
+    ("cmdg_ocean_tendency_from_slow_to_fast", C.c_int, [_vp, _vp, _vp, _vp]),
+    ("cmdg_ocean_reconcile_from_fast_to_slow", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    ("cmdg_lsrk_update", C.c_int, [_vp, _vp, _vp, _d, _d]),
+    ("cmdg_split_explicit_step", C.c_int,
+     [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i32, _vp, _vp, _vp]),
     ("cmdg_profile_enable", C.c_int, [_vp, _i32]),
     ("cmdg_profile_get", C.c_int, [_vp, _i32, _vp, _vp]),
     ("cmdg_profile_reset", C.c_int, [_vp]),

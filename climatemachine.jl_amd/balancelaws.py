@@ -22,6 +22,7 @@ PHYSICS_ADVECTION_DIFFUSION = 1
 PHYSICS_DRY_ATMOS = 2
 PHYSICS_HYDROSTATIC_BOUSSINESQ = 3
 PHYSICS_PRESSURE_GRADIENT = 4
+PHYSICS_SHALLOW_WATER = 5
 
 __all__ = [
     "EveryDirection", "HorizontalDirection", "VerticalDirection",

@@ -85,6 +85,7 @@ EngineBase::~EngineBase()
     if (d_partial) hipFree(d_partial);
     if (d_elemred) hipFree(d_elemred);
     if (d_Imat) hipFree(d_Imat);
+    if (d_flowint) hipFree(d_flowint);
     if (ev_comp) hipEventDestroy(ev_comp);
     if (nccl_comm && rccl::CommDestroy) rccl::CommDestroy(nccl_comm);
     if (s_comp) hipStreamDestroy(s_comp);
@@ -585,7 +586,8 @@ int EngineBase::set_hooks(const cmdg_rhs_hooks *hk)
     if (hk->npre < 0 || hk->npre > CMDG_MAX_HOOK_OPS || hk->ncopy < 0 || hk->ncopy > CMDG_MAX_HOOK_OPS ||
         hk->nsurf < 0 || hk->nsurf > CMDG_MAX_HOOK_OPS)
         return fail(CMDG_ERR_INVALID, "hooks: too many operations");
-    const bool cols = hk->has_integral || hk->has_reverse_integral || hk->nsurf > 0;
+    const bool cols = hk->has_integral || hk->has_reverse_integral || hk->nsurf > 0 ||
+                      hk->has_flow_deviation;
     if (cols && (!stacked || hk->nvertelem < 1 || nreal % hk->nvertelem || nghost % hk->nvertelem))
         return fail(CMDG_ERR_INVALID, "hooks: column operators need a stacked topology and nvertelem");
     for (int i = 0; i < hk->ncopy; ++i)
@@ -598,7 +600,13 @@ int EngineBase::set_hooks(const cmdg_rhs_hooks *hk)
             return fail(CMDG_ERR_INVALID, "hooks: surface column out of range");
     for (int i = 0; i < hk->npre; ++i)
         if (!hk->pre_filter[i]) return fail(CMDG_ERR_INVALID, "hooks: NULL filter");
-    if (hk->has_integral) {
+    if (hk->has_flow_deviation) {
+        if (hk->flow_u_col < 0 || hk->flow_u_col + 2 > ns || hk->flow_ud_col < 0 ||
+            hk->flow_ud_col + 2 > naux || !(hk->flow_H > 0))
+            return fail(CMDG_ERR_INVALID, "hooks: flow deviation columns / depth");
+        if (!d_flowint) HIPCHK(hipMalloc(&d_flowint, sizeof(double) * 2 * Np * nelem));
+    }
+    if (hk->has_integral || hk->has_flow_deviation) {
         if (!hk->Imat) return fail(CMDG_ERR_INVALID, "hooks: Imat is NULL");
         if (!d_Imat) HIPCHK(hipMalloc(&d_Imat, sizeof(double) * NQ * NQ));
         HIPCHK(hipMemcpy(d_Imat, hk->Imat, sizeof(double) * NQ * NQ, hipMemcpyHostToDevice));
@@ -614,7 +622,33 @@ int EngineBase::run_pre_hooks(const RhsCtx &c)
     for (int i = 0; i < hooks.npre; ++i)
         if (int r = filter_apply(reinterpret_cast<const FilterObj *>(hooks.pre_filter[i]), c.Qin, ns))
             return r;
+    if (hooks.has_flow_deviation) {
+        // compute_flow_deviation!(dg, ::HBModel, ::Coupled, Q, t)
+        // (HydrostaticBoussinesqCoupling.jl:43-85): u_d = u - (1/H) int u dz
+        if (int r = integrate_velocity(c.Qin, ns, hooks.flow_u_col, hooks.nvertelem)) return r;
+        const int64_t n = (int64_t)nreal * Np;
+        hipLaunchKernelGGL(k_column_minus_top_over_H, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)),
+                           dim3(256), 0, s_comp, aux, naux, hooks.flow_ud_col, (const double *)c.Qin, ns,
+                           hooks.flow_u_col, (const double *)d_flowint, hooks.flow_H, NQ * NQ, NQ,
+                           hooks.nvertelem, (int64_t)(nreal / hooks.nvertelem));
+    }
     return CMDG_OK;
+}
+
+// update_auxiliary_state!(integral_model, ...) of VerticalIntegralModel.jl:60-81: the upward
+// column integral of X[:, col..col+1, :] into the scratch d_flowint (Np, 2, nelem)
+int EngineBase::integrate_velocity(const double *X, int nstate, int col, int nvert)
+{
+    if (!d_flowint) HIPCHK(hipMalloc(&d_flowint, sizeof(double) * 2 * Np * nelem));
+    cmdg_stack_integral_desc d{};
+    d.nout = 2;
+    for (int c = 0; c < 2; ++c) {
+        d.src_is_state[c] = 1;
+        d.src_col[c] = col + c;
+        d.scale[c] = 1.0;
+        d.dst_col[c] = c;
+    }
+    return stack_integral(false, X, nstate, d_flowint, 2, nvert, nullptr, &d, 0, nreal / nvert);
 }
 
 int EngineBase::run_gradient_hooks(const RhsCtx &c, int64_t e0, int64_t e1)
@@ -798,11 +832,6 @@ int EngineBase::wsum2(const double *A, const double *B, int nvar, int weighted, 
 // =====================================================================================
 using namespace cmdg;
 
-struct cmdg_context {
-    EngineBase *eng = nullptr;
-    std::string err;
-};
-
 static thread_local std::string g_create_err;
 
 static int set_err(cmdg_handle h, int code)
@@ -836,6 +865,7 @@ int cmdg_physics_counts(int32_t physics_id, const int32_t *iparam, int32_t out[6
     case CMDG_PHYSICS_DRY_ATMOS: return counts_atmos(iparam, out);
     case CMDG_PHYSICS_HYDROSTATIC_BOUSSINESQ: return counts_ocean(iparam, out);
     case CMDG_PHYSICS_PRESSURE_GRADIENT: return counts_pgrad(iparam, out);
+    case CMDG_PHYSICS_SHALLOW_WATER: return counts_sw(iparam, out);
     default: return CMDG_ERR_UNSUPPORTED;
     }
 }
@@ -860,6 +890,7 @@ int cmdg_create(const cmdg_desc *d, cmdg_handle *out)
     case CMDG_PHYSICS_DRY_ATMOS: e = make_engine_atmos(d, err); break;
     case CMDG_PHYSICS_HYDROSTATIC_BOUSSINESQ: e = make_engine_ocean(d, err); break;
     case CMDG_PHYSICS_PRESSURE_GRADIENT: e = make_engine_pgrad(d, err); break;
+    case CMDG_PHYSICS_SHALLOW_WATER: e = make_engine_sw(d, err); break;
     default: err = "unknown physics_id"; break;
     }
     if (!e) {

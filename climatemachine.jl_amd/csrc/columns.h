@@ -139,4 +139,116 @@ static __global__ void k_surface_to_column(double *__restrict__ aux, int naux, i
     }
 }
 
+// dst[(i,j,k), dcol + c, e] = src[(i,j,k), scol + c, e] - top[(i,j), c, stack] / H for c = 0, 1,
+// where top is the value of the column integral `ia` (Np, 2, nelem) at the top node of the top
+// element.  dst == src, dcol == scol gives the in-place `dG_u .-= int du / H` of
+// Communication.jl:64-65; dst = aux.u_d, src = Q.u the flow deviation of
+// HydrostaticBoussinesqCoupling.jl:78-84.
+static __global__ void k_column_minus_top_over_H(double *__restrict__ dst, int ndst, int dcol,
+                                                 const double *src, int nsrc, int scol,
+                                                 const double *__restrict__ ia, double H, int Nij,
+                                                 int Nqk, int nvert, int64_t nhorz)
+{
+    const int Np = Nij * Nqk;
+    const int64_t n = nhorz * nvert * Np;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int ijk = (int)(i % Np);
+        const int64_t e = i / Np;
+        const int64_t et = (nvert - 1) + (e / nvert) * nvert;
+        const int top = ijk % Nij + Nij * (Nqk - 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double T = ia[top + (int64_t)Np * (c + 2 * et)];
+            dst[ijk + (int64_t)Np * (dcol + c + (int64_t)ndst * e)] =
+                src[ijk + (int64_t)Np * (scol + c + (int64_t)nsrc * e)] - T / H;
+        }
+    }
+}
+
+// layer[(i,j,k2), lcol + c, eh] = top[(i,j), c, stack eh]: `G_U .= int du` onto the one-layer
+// extrusion of the 2-D grid (Communication.jl:59-61)
+static __global__ void k_top_to_layer(double *__restrict__ layer, int nlayer, int lcol,
+                                      const double *__restrict__ ia, int Nij, int Nqk3, int nvert,
+                                      int Nqk2, int64_t nhorz)
+{
+    const int Np3 = Nij * Nqk3, Np2 = Nij * Nqk2;
+    const int64_t n = nhorz * Np2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int ijk = (int)(i % Np2);
+        const int64_t eh = i / Np2;
+        const int64_t et = (nvert - 1) + eh * nvert;
+        const int top = ijk % Nij + Nij * (Nqk3 - 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            layer[ijk + (int64_t)Np2 * (lcol + c + (int64_t)nlayer * eh)] =
+                ia[top + (int64_t)Np3 * (c + 2 * et)];
+    }
+}
+
+// reconcile_from_fast_to_slow! (Communication.jl:100-170), 2-D part: A2.du = 1/H (U - int u)
+static __global__ void k_reconcile_layer(double *__restrict__ A2, int naux2, int ducol,
+                                         const double *__restrict__ Q2, int ns2, int Ucol,
+                                         const double *__restrict__ ia, double H, int Nij,
+                                         int Nqk3, int nvert, int Nqk2, int64_t nhorz)
+{
+    const int Np3 = Nij * Nqk3, Np2 = Nij * Nqk2;
+    const int64_t n = nhorz * Np2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int ijk = (int)(i % Np2);
+        const int64_t eh = i / Np2;
+        const int64_t et = (nvert - 1) + eh * nvert;
+        const int ij = ijk % Nij;
+        const int top = ij + Nij * (Nqk3 - 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double U = Q2[ij + (int64_t)Np2 * (Ucol + c + (int64_t)ns2 * eh)];
+            A2[ijk + (int64_t)Np2 * (ducol + c + (int64_t)naux2 * eh)] =
+                1 / H * (U - ia[top + (int64_t)Np3 * (c + 2 * et)]);
+        }
+    }
+}
+
+// ... 3-D part: Q3.u += du through the column, Q3.eta = Q2.eta
+static __global__ void k_reconcile_column(double *__restrict__ Q3, int ns3, int ucol, int etacol,
+                                          const double *__restrict__ Q2, int ns2, int Ucol,
+                                          int eta2col, const double *__restrict__ ia, double H,
+                                          int Nij, int Nqk3, int nvert, int Nqk2, int64_t nhorz)
+{
+    const int Np3 = Nij * Nqk3, Np2 = Nij * Nqk2;
+    const int64_t n = nhorz * nvert * Np3;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int ijk = (int)(i % Np3);
+        const int64_t e = i / Np3;
+        const int64_t eh = e / nvert;
+        const int64_t et = (nvert - 1) + eh * nvert;
+        const int ij = ijk % Nij;
+        const int top = ij + Nij * (Nqk3 - 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double U = Q2[ij + (int64_t)Np2 * (Ucol + c + (int64_t)ns2 * eh)];
+            const double du = 1 / H * (U - ia[top + (int64_t)Np3 * (c + 2 * et)]);
+            Q3[ijk + (int64_t)Np3 * (ucol + c + (int64_t)ns3 * e)] += du;
+        }
+        Q3[ijk + (int64_t)Np3 * (etacol + (int64_t)ns3 * e)] =
+            Q2[ij + (int64_t)Np2 * (eta2col + (int64_t)ns2 * eh)];
+    }
+}
+
+// aux[:, col .. col + ncol - 1, real elements] = value
+static __global__ void k_fill_columns(double *__restrict__ A, int nA, int col, int ncol,
+                                      double value, int Np, int64_t nelems)
+{
+    const int64_t n = nelems * ncol * Np;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i / ((int64_t)ncol * Np);
+        const int r = (int)(i % ((int64_t)ncol * Np));
+        A[r + (int64_t)Np * (col + (int64_t)nA * e)] = value;
+    }
+}
+
 }  // namespace cmdg

@@ -129,6 +129,8 @@ struct EngineBase {
     cmdg_rhs_hooks hooks{};
     int set_hooks(const cmdg_rhs_hooks *hk);
     int run_pre_hooks(const RhsCtx &c);
+    int integrate_velocity(const double *X, int nstate, int col, int nvert);
+    double *d_flowint = nullptr;  // (Np, 2, nelem) column integral of the horizontal velocity
     int run_gradient_hooks(const RhsCtx &c, int64_t e0, int64_t e1);
     double *d_Imat = nullptr;
     int filter_create(const cmdg_filter_desc *d, FilterObj **out);
@@ -139,6 +141,15 @@ struct EngineBase {
     void prof_end(hipStream_t st);
     void prof_collect();
 };
+
+}  // namespace cmdg
+
+struct cmdg_context {
+    cmdg::EngineBase *eng = nullptr;
+    std::string err;
+};
+
+namespace cmdg {
 
 int group_rhs(std::vector<EngineBase *> &g, std::vector<RhsCtx> &c);
 int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, double t, double dt,
@@ -286,6 +297,8 @@ EngineBase *make_engine_atmos(const cmdg_desc *d, std::string &err);
 int counts_atmos(const int32_t *iparam, int32_t out[6]);
 EngineBase *make_engine_ocean(const cmdg_desc *d, std::string &err);
 int counts_ocean(const int32_t *iparam, int32_t out[6]);
+EngineBase *make_engine_sw(const cmdg_desc *d, std::string &err);
+int counts_sw(const int32_t *iparam, int32_t out[6]);
 EngineBase *make_engine_pgrad(const cmdg_desc *d, std::string &err);
 int counts_pgrad(const int32_t *iparam, int32_t out[6]);
 

@@ -3,6 +3,7 @@
 #include "engine.h"
 #include "physics_ocean.h"
 #include "physics_pgrad.h"
+#include "physics_sw.h"
 
 namespace cmdg {
 
@@ -26,6 +27,34 @@ EngineBase *make_engine_ocean(const cmdg_desc *d, std::string &err)
     case 5: return make_engine<HydroBoussinesq, 6>(d);
     default:
         err = "HydrostaticBoussinesq: polynomial order not compiled in (have N = 2..5)";
+        return nullptr;
+    }
+}
+
+int counts_sw(const int32_t *ip, int32_t out[6])
+{
+    out[0] = 3;
+    out[1] = 5;
+    out[2] = ShallowWater::NGRAD;
+    out[3] = ShallowWater::NGF;
+    out[4] = out[5] = 0;
+    (void)ip;
+    return CMDG_OK;
+}
+
+EngineBase *make_engine_sw(const cmdg_desc *d, std::string &err)
+{
+    if (d->iparam[1] != 0) {
+        err = "ShallowWaterModel: LinearDrag is not compiled in (ConstantViscosity only)";
+        return nullptr;
+    }
+    switch (d->N[0]) {
+    case 2: return make_engine<ShallowWater, 3>(d);
+    case 3: return make_engine<ShallowWater, 4>(d);
+    case 4: return make_engine<ShallowWater, 5>(d);
+    case 5: return make_engine<ShallowWater, 6>(d);
+    default:
+        err = "ShallowWaterModel: polynomial order not compiled in (have N = 2..5)";
         return nullptr;
     }
 }

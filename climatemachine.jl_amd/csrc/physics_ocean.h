@@ -8,7 +8,8 @@
 // integrals) are operator hooks (cmdg_set_rhs_hooks), not part of this functor.
 //
 // Parameter block: iparam[0] momentum advection, [1] tracer advection, [2] Coriolis (0 fixed
-// box f = -0, 1 rotating f = f_o, 2 beta plane), [6] nbc, [7..13] bc = velocity kind + 8 *
+// box f = -0, 1 rotating f = f_o, 2 beta plane), [3] coupling (1 = Coupled(): the baroclinic half
+// of the split-explicit pair, src/Ocean/SplitExplicit/HydrostaticBoussinesqCoupling.jl), [6] nbc, [7..13] bc = velocity kind + 8 *
 // temperature kind (velocity 1 Impenetrable(NoSlip), 2 Impenetrable(FreeSlip), 3
 // Penetrable(FreeSlip), 4 Impenetrable(KinematicStress), 5 Penetrable(KinematicStress);
 // temperature 0 Insulating, 1 TemperatureFlux -- stress and flux of the OceanGyre problem,
@@ -20,7 +21,7 @@
 namespace cmdg {
 
 struct OceanParams {
-    int madv, tadv, cor, nbc;
+    int madv, tadv, cor, coupled, nbc;
     int bc[8];
     double grav, ch, cz, aT, nuh, nuz, kh, kz, kc, fo, beta, tau_o, rho_o, Ly, lam_r, thE;
 };
@@ -28,7 +29,7 @@ struct OceanParams {
 struct HydroBoussinesq {
     using Params = OceanParams;
     enum { U = 0, V = 1, ETA = 2, TH = 3 };
-    enum { AY = 0, AW = 1, APKIN = 2, AWZ0 = 3 };
+    enum { AY = 0, AW = 1, APKIN = 2, AWZ0 = 3, AUD = 4 };
     enum { GDIVH = 0, GNU = 1, GKAPPA = 7 };
     static constexpr int NS = 4, NAUX = 8, NGRAD = 5, NGF = 10, NGL = 0, NHYP = 0;
     static constexpr bool HAS_UPDATE_AUX = false, FUSE_UPDATE_AUX = false, HAS_SOURCE = true;
@@ -46,6 +47,7 @@ struct HydroBoussinesq {
         p.madv = ip[0];
         p.tadv = ip[1];
         p.cor = ip[2];
+        p.coupled = ip[3];
         p.nbc = ip[6];
         for (int i = 0; i < 7; ++i) p.bc[i] = ip[7 + i];
         p.bc[7] = 0;
@@ -76,7 +78,7 @@ struct HydroBoussinesq {
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 const double I = d == c ? 1.0 : -0.0;  // I^h (3 x 2)
-                F[d + 3 * c] += ge * I;
+                if (!m.coupled) F[d + 3 * c] += ge * I;  // hydrostatic_pressure! (Uncoupled only)
                 F[d + 3 * c] += gp * I;
             }
         const double v[3] = {Q[U], Q[V], aux[AW]};
@@ -109,20 +111,29 @@ struct HydroBoussinesq {
     {
         S[ETA] += aux[AWZ0];
         const double f = coriolis(m, aux[AY]);
-        S[U] -= -f * Q[V];
-        S[V] -= f * Q[U];
+        if (m.coupled) {  // coriolis_force!(::Coupled): deviation from the vertical mean
+            S[U] -= -f * aux[AUD + 1];
+            S[V] -= f * aux[AUD];
+        } else {
+            S[U] -= -f * Q[V];
+            S[V] -= f * Q[U];
+        }
         S[U] += 0;  // forcing: noforcing(args...) = 0
         S[V] += 0;
         S[ETA] += 0;
         S[TH] += 0;
     }
     __device__ static void init_derived(const Params &, double *, const double *) {}
-    __device__ static void gradient_argument(const Params &, double *G, const double *Q,
-                                             const double *, double)
+    __device__ static void gradient_argument(const Params &m, double *G, const double *Q,
+                                             const double *aux, double)
     {
         G[4] = Q[TH];
         G[0] = Q[U];
         G[1] = Q[V];
+        if (m.coupled) {  // velocity_gradient_argument!(::Coupled)
+            G[2] = aux[AUD];
+            G[3] = aux[AUD + 1];
+        }
     }
     __device__ static void gradient_flux(const Params &m, double *D, const double *g,
                                          const double *, const double *, double)
@@ -132,7 +143,11 @@ struct HydroBoussinesq {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int d = 0; d < 3; ++d) D[GNU + d + 3 * c] = -nu[d] * g[d + 3 * c];
+            for (int d = 0; d < 3; ++d) {
+                // Coupled: horizontal derivatives of u_d, vertical derivative of u
+                const double gu = (m.coupled && d < 2) ? g[d + 3 * (2 + c)] : g[d + 3 * c];
+                D[GNU + d + 3 * c] = -nu[d] * gu;
+            }
         const double kap[3] = {m.kh, m.kh, g[2 + 3 * 4] < 0 ? m.kc : m.kz};
 #pragma unroll
         for (int d = 0; d < 3; ++d) D[GKAPPA + d] = -kap[d] * g[d + 3 * 4];

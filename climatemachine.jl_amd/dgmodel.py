@@ -230,11 +230,12 @@ class DGModel:
             C.byref(d)), self.handle)
 
     def set_rhs_hooks(self, pre_filters=(), gradflux_to_aux=(), integral=None,
-                      reverse_integral=None, surface_to_column=()):
+                      reverse_integral=None, surface_to_column=(), flow_deviation=None):
         """The composition a law's ``update_auxiliary_state!`` /
         ``update_auxiliary_state_gradient!`` overrides stand for (see ``cmdg_rhs_hooks`` in
         include/cmdg.h); ``set_rhs_hooks()`` with no arguments clears them."""
-        if not (pre_filters or gradflux_to_aux or integral or reverse_integral or surface_to_column):
+        if not (pre_filters or gradflux_to_aux or integral or reverse_integral
+                or surface_to_column or flow_deviation):
             self._hooks = None
             _lib.check(self.L.cmdg_set_rhs_hooks(self.handle, None), self.handle)
             return
@@ -263,6 +264,10 @@ class DGModel:
         hk.nsurf = len(surface_to_column)
         for i, (a, b) in enumerate(surface_to_column):
             hk.surf_src_col[i], hk.surf_dst_col[i] = int(a), int(b)
+        if flow_deviation:      # (state column of u, auxiliary column of u_d, depth H)
+            hk.has_flow_deviation = 1
+            hk.flow_u_col, hk.flow_ud_col = int(flow_deviation[0]), int(flow_deviation[1])
+            hk.flow_H = float(flow_deviation[2])
         hk.nvertelem = int(self.grid.topology.stacksize or 0)
         Imat = np.ascontiguousarray(np.asarray(self.grid.Imat[-1], dtype=np.float64).T)
         hk.Imat = Imat.ctypes.data

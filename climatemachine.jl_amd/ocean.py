@@ -16,10 +16,11 @@ theta`` (10).  The law's ``update_auxiliary_state!`` (filters) and
 import numpy as np
 from scipy.linalg import expm
 
-from .balancelaws import PHYSICS_HYDROSTATIC_BOUSSINESQ
+from .balancelaws import PHYSICS_HYDROSTATIC_BOUSSINESQ, PHYSICS_SHALLOW_WATER
 from .mesh import filters as F
 
-__all__ = ["HydrostaticBoussinesqModel", "SimpleBox", "OceanGyre", "HomogeneousBox", "OceanBC",
+__all__ = ["HydrostaticBoussinesqModel", "ShallowWaterModel", "extruded_barotropic_grid",
+           "SimpleBox", "OceanGyre", "HomogeneousBox", "OceanBC",
            "IMPENETRABLE_NOSLIP", "IMPENETRABLE_FREESLIP", "PENETRABLE_FREESLIP",
            "IMPENETRABLE_KINEMATIC_STRESS", "PENETRABLE_KINEMATIC_STRESS", "INSULATING",
            "TEMPERATURE_FLUX", "install_hydrostatic_boussinesq_hooks"]
@@ -101,8 +102,11 @@ class HydrostaticBoussinesqModel:
 
     def __init__(self, problem, momentum_advection=False, tracer_advection=True, rho_o=1000.0,
                  c_h=0.0, c_z=0.0, alpha_T=2e-4, nu_h=5e3, nu_z=5e-3, kappa_h=1e3, kappa_z=1e-4,
-                 kappa_c=1e-1, f_o=1e-4, beta=1e-11, grav=9.81):
+                 kappa_c=1e-1, f_o=1e-4, beta=1e-11, grav=9.81, coupled=False):
         self.problem = problem
+        # Coupled(): the baroclinic half of the split-explicit pair
+        # (src/Ocean/SplitExplicit/HydrostaticBoussinesqCoupling.jl)
+        self.coupled = bool(coupled)
         self.momentum_advection, self.tracer_advection = bool(momentum_advection), bool(tracer_advection)
         self.rho_o, self.c_h, self.c_z, self.alpha_T = rho_o, c_h, c_z, alpha_T
         self.nu_h, self.nu_z, self.kappa_h, self.kappa_z, self.kappa_c = nu_h, nu_z, kappa_h, kappa_z, kappa_c
@@ -115,6 +119,7 @@ class HydrostaticBoussinesqModel:
         ip = np.zeros(16, dtype=np.int32)
         ip[0], ip[1] = int(self.momentum_advection), int(self.tracer_advection)
         ip[2] = self.problem.rotation
+        ip[3] = int(self.coupled)
         bcs = self.problem.boundary_conditions
         ip[6] = len(bcs)
         for i, bc in enumerate(bcs):
@@ -141,6 +146,67 @@ class HydrostaticBoussinesqModel:
         return Q
 
 
+class ShallowWaterModel:
+    """``ShallowWaterModel{FT}(param_set, problem, turbulence, advection; coupling, c, f_o, beta)``
+    (src/Ocean/ShallowWater/ShallowWaterModel.jl:60-86): state ``eta, U[2]``; auxiliary
+    ``y, G_U[2], Delta_u[2]``; gradient ``U[2]``; gradient flux ``nu grad U`` (3 x 2).
+    The barotropic half of the split-explicit pair.  It is a 2-D law in the reference; here
+    it runs on the 3-D kernels over :func:`extruded_barotropic_grid` (fields constant along the
+    extrusion; the third flux component is identically zero)."""
+    physics_id = PHYSICS_SHALLOW_WATER
+    ns, naux, ngrad, ngradflux, ngradlap, nhyper = 3, 5, 2, 6, 0, 0
+
+    def __init__(self, problem, nu, advection=False, coupled=False, c=0.0, f_o=1e-4, beta=1e-11,
+                 grav=9.81):
+        self.problem, self.nu, self.advection, self.coupled = problem, nu, bool(advection), bool(coupled)
+        self.c, self.f_o, self.beta, self.grav = c, f_o, beta, grav
+
+    def state_names(self):
+        return ["η", "U[1]", "U[2]"]
+
+    def descriptor(self):
+        ip = np.zeros(16, dtype=np.int32)
+        ip[0], ip[1], ip[2], ip[3] = int(self.advection), 0, self.problem.rotation, int(self.coupled)
+        dp = np.zeros(32)
+        dp[0:6] = [self.grav, self.problem.H, self.c, self.nu, self.f_o, self.beta]
+        return ip, dp
+
+    def init_state_auxiliary(self, grid):
+        """``ocean_init_aux!(::SWModel, ...)`` (simple_box_problem.jl:33-38)."""
+        aux = np.full((grid.nelem, self.naux, grid.Np), -0.0)
+        aux[:, 0, :] = grid.vgeo[:, 13, :]
+        return aux
+
+    def init_state_prognostic(self, grid, aux, t):
+        """``ocean_init_state!(::SWModel, ::SimpleBox, ...)`` (simple_box_problem.jl:128-146):
+        the barotropic mode ``U = A1 sin(kx x)``, ``eta = A2 cos(kx x)``, ``A = exp(M t) [1, 1]``."""
+        p = self.problem
+        assert p.rotation == FIXED
+        x = grid.vgeo[:, 12, :]
+        kx = 2 * np.pi / p.Lx
+        gH = self.grav * p.H
+        A = expm(np.array([[-self.nu * kx ** 2, gH * kx], [-kx, 0.0]]) * t) @ np.array([1.0, 1.0])
+        Q = np.zeros((grid.nelem, 3, grid.Np))
+        Q[:, 0] = A[1] * np.cos(kx * x)
+        Q[:, 1] = A[0] * np.sin(kx * x)
+        Q[:, 2] = -0.0
+        return Q
+
+
+def extruded_barotropic_grid(xrange, yrange, N, periodicity=(True, True), boundary=((0, 0), (0, 0)),
+                             connectivity="full", rank=0, size=1):
+    """One periodic layer of unit height over the horizontal brick mesh ``xrange x yrange``:
+    the grid the 2-D barotropic model runs on with the 3-D kernels.  Built by the same stacked
+    topology as the 3-D ocean grid, so element ``eh`` of it sits under the stack
+    ``eh * nvert .. (eh + 1) * nvert - 1`` of the 3-D grid."""
+    from . import mesh as M
+    rng = [np.asarray(xrange), np.asarray(yrange), np.array([0.0, 1.0])]
+    topl = M.StackedBrickTopology(rng, periodicity=(periodicity[0], periodicity[1], True),
+                                  boundary=(boundary[0], boundary[1], (0, 0)),
+                                  connectivity=connectivity, rank=rank, size=size)
+    return M.DiscontinuousSpectralElementGrid(topl, N)
+
+
 def install_hydrostatic_boussinesq_hooks(dg, vert_filter=None, exp_filter=None):
     """``modeldata = (vert_filter, exp_filter)`` of the ocean driver + the two law methods
     (hydrostatic_boussinesq_model.jl:654-726) as hooks of the device operator:
@@ -152,11 +218,79 @@ def install_hydrostatic_boussinesq_hooks(dg, vert_filter=None, exp_filter=None):
     exp_filter = exp_filter or F.ExponentialFilter(g, 1, 8)
     fu = F.make_device_filter(dg, vert_filter, F.FilterIndices(1, 2), direction=F.VerticalDirection)
     ft = F.make_device_filter(dg, exp_filter, F.FilterIndices(4), direction=F.VerticalDirection)
+    # Coupled(): u_d = u - (vertical mean of u) after the filters
+    # (HydrostaticBoussinesqCoupling.jl:43-85); state u = columns 0, 1, aux u_d = columns 4, 5
+    flow = (0, 4, law.problem.H) if getattr(law, "coupled", False) else None
     dg.set_rhs_hooks(
         pre_filters=[fu, ft],
         gradflux_to_aux=[(0, 1, -1.0)],                     # A.w = -D.div_h u
         integral=dict(src=[(0, 1), (1, 3)], scale=[1.0, -law.alpha_T], dst=[1, 2]),
         reverse_integral=dict(rsrc=[2], rdst=[2]),
         surface_to_column=[(1, 3)],                          # w at the top node -> wz0
+        flow_deviation=flow,
     )
     return fu, ft
+
+
+class SplitExplicitLSRK2nSolver:
+    """``SplitExplicitLSRK2nSolver(slow_solver, fast_solver)`` of
+    src/Numerics/ODESolvers/SplitExplicitMethod.jl:21-86 over two device operators: ``dg_slow``
+    the 3-D HydrostaticBoussinesqModel (with its hooks installed), ``dg_fast`` the
+    ShallowWaterModel on ``extruded_barotropic_grid``.  ``dostep`` advances both states in
+    place by ``nsteps`` slow steps; the coupling runs when the slow law is ``Coupled``."""
+
+    def __init__(self, dg_slow, dg_fast, Q_slow, Q_fast, dt_slow, dt_fast, t0=0.0,
+                 coefficients=None):
+        from . import _lib
+        from .odesolvers import LSRK54CarpenterKennedy
+        import ctypes as C
+        self.dg_slow, self.dg_fast = dg_slow, dg_fast
+        self.dt, self.dt_fast, self.t, self.steps = float(dt_slow), float(dt_fast), float(t0), 0
+        if coefficients is None:
+            ref = LSRK54CarpenterKennedy(dg_fast, Q_fast)
+            coefficients = (ref.RKA, ref.RKB, ref.RKC)
+            self.dQ_fast = ref.dQ
+        else:
+            self.dQ_fast = dg_fast.create_state(Q_fast.shape[1])
+        self.RKA, self.RKB, self.RKC = (np.asarray(c, dtype=np.float64) for c in coefficients)
+        self.dQ_slow = dg_slow.create_state(Q_slow.shape[1])
+        self.dQ2fast = dg_slow.create_state(Q_slow.shape[1])
+        law, g = dg_slow.balance_law, dg_slow.grid
+        self.coupled = bool(getattr(law, "coupled", False))
+        d = _lib.CmdgOceanCouplingDesc()
+        d.nvertelem, d.H = int(g.topology.stacksize), float(law.problem.H)
+        self._Imat = np.ascontiguousarray(np.asarray(g.Imat[-1], dtype=np.float64).T)
+        d.Imat = self._Imat.ctypes.data
+        d.slow_u_col, d.slow_eta_col, d.slow_dGu_col = 0, 2, 6
+        d.fast_eta_col, d.fast_U_col, d.fast_GU_col, d.fast_du_col = 0, 1, 1, 3
+        self.desc, self._C, self._lib = d, C, _lib
+
+    def dostep(self, Q_slow, Q_fast, nsteps=1):
+        C, L = self._C, self.dg_slow.L
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        self.dg_slow._torch_ready()
+        for _ in range(int(nsteps)):
+            self._lib.check(L.cmdg_split_explicit_step(
+                self.dg_slow.handle, self.dg_fast.handle, C.byref(self.desc), int(self.coupled),
+                Q_slow.data_ptr(), self.dQ_slow.data_ptr(), self.dQ2fast.data_ptr(),
+                Q_fast.data_ptr(), self.dQ_fast.data_ptr(), self.t, self.dt, self.dt_fast,
+                len(self.RKA), p(self.RKA), p(self.RKB), p(self.RKC)), self.dg_slow.handle)
+            self.steps += 1
+            self.t += self.dt      # (the reference accumulates time the same way)
+        self.dg_slow.synchronize()
+        self.dg_fast.synchronize()
+
+    # the exchange functions on their own (src/Ocean/SplitExplicit/Communication.jl)
+    def initialize_states(self):
+        self._lib.check(self.dg_slow.L.cmdg_ocean_initialize_states(
+            self.dg_slow.handle, self.dg_fast.handle, self._C.byref(self.desc)), self.dg_slow.handle)
+
+    def tendency_from_slow_to_fast(self, dQ_slow):
+        self._lib.check(self.dg_slow.L.cmdg_ocean_tendency_from_slow_to_fast(
+            self.dg_slow.handle, self.dg_fast.handle, self._C.byref(self.desc),
+            dQ_slow.data_ptr()), self.dg_slow.handle)
+
+    def reconcile_from_fast_to_slow(self, Q_slow, Q_fast):
+        self._lib.check(self.dg_slow.L.cmdg_ocean_reconcile_from_fast_to_slow(
+            self.dg_slow.handle, self.dg_fast.handle, self._C.byref(self.desc),
+            Q_slow.data_ptr(), Q_fast.data_ptr()), self.dg_slow.handle)

@@ -43,7 +43,9 @@ enum { CMDG_RUSANOV = 0, CMDG_CENTRAL_FIRST_ORDER = 1 };
 enum {
     CMDG_PHYSICS_ADVECTION_DIFFUSION = 1, CMDG_PHYSICS_DRY_ATMOS = 2,
     CMDG_PHYSICS_HYDROSTATIC_BOUSSINESQ = 3,
-    CMDG_PHYSICS_PRESSURE_GRADIENT = 4 /* PressureGradientModel, ref_state.jl:196-233 */
+    CMDG_PHYSICS_PRESSURE_GRADIENT = 4, /* PressureGradientModel, ref_state.jl:196-233 */
+    CMDG_PHYSICS_SHALLOW_WATER = 5      /* ShallowWaterModel (barotropic half of the split-explicit
+                                           ocean), on a one-layer extrusion of the 2-D grid */
 };
 
 /* Construction record: the fields of `DGModel(balance_law, grid, nf1, nf2, nfgrad;
@@ -270,9 +272,57 @@ typedef struct cmdg_rhs_hooks {
     int32_t surf_src_col[CMDG_MAX_HOOK_OPS], surf_dst_col[CMDG_MAX_HOOK_OPS];
     int32_t nvertelem;
     const double *Imat; /* HOST (Nq, Nq) column-major grid.Imat[dim] */
+    /* compute_flow_deviation!(dg, ::HBModel, ::Coupled, Q, t)
+     * (src/Ocean/SplitExplicit/HydrostaticBoussinesqCoupling.jl:43-85), run after the pre
+     * filters: aux[flow_ud_col + c] = Q[flow_u_col + c] - (1 / flow_H) * (column integral of
+     * Q[flow_u_col + c]), c = 0, 1 */
+    int32_t has_flow_deviation, flow_u_col, flow_ud_col;
+    double flow_H;
 } cmdg_rhs_hooks;
 /* hooks == NULL clears them.  Filters must outlive their use. */
 int cmdg_set_rhs_hooks(cmdg_handle h, const cmdg_rhs_hooks *hooks);
+
+/* ---- split-explicit ocean (src/Numerics/ODESolvers/SplitExplicitMethod.jl:1-190 and
+ * src/Ocean/SplitExplicit/Communication.jl) --------------------------------------------
+ * `slow` is the 3-D HydrostaticBoussinesqModel handle (Coupled), `fast` the ShallowWaterModel
+ * handle on the one-layer extrusion of the 2-D grid; both share the horizontal element order
+ * and the horizontal polynomial order.  Columns are 0-based; vector fields take two
+ * consecutive columns. */
+typedef struct cmdg_ocean_coupling_desc {
+    int32_t nvertelem;  /* stack size of the slow grid */
+    double H;           /* problem.H */
+    const double *Imat; /* HOST (Nq, Nq) column-major vertical grid.Imat of the slow grid */
+    int32_t slow_u_col, slow_eta_col;  /* slow state: u[2], eta */
+    int32_t slow_dGu_col;              /* slow auxiliary: dG_u[2] */
+    int32_t fast_eta_col, fast_U_col;  /* fast state: eta, U[2] */
+    int32_t fast_GU_col, fast_du_col;  /* fast auxiliary: G_U[2], Delta_u[2] */
+} cmdg_ocean_coupling_desc;
+/* initialize_states! (Communication.jl:1-12): slow.aux.dG_u = -0 */
+int cmdg_ocean_initialize_states(cmdg_handle slow, cmdg_handle fast,
+                                 const cmdg_ocean_coupling_desc *d);
+/* tendency_from_slow_to_fast! (Communication.jl:14-70): int du = column integral of the
+ * slow tendency dQ_slow's u; fast.aux.G_U = int du, slow.aux.dG_u -= int du / H */
+int cmdg_ocean_tendency_from_slow_to_fast(cmdg_handle slow, cmdg_handle fast,
+                                          const cmdg_ocean_coupling_desc *d,
+                                          const double *dQ_slow);
+/* reconcile_from_fast_to_slow! (Communication.jl:100-170): fast.aux.Delta_u = 1/H (U - int u),
+ * Q_slow.u += Delta_u through the column, Q_slow.eta = Q_fast.eta */
+int cmdg_ocean_reconcile_from_fast_to_slow(cmdg_handle slow, cmdg_handle fast,
+                                           const cmdg_ocean_coupling_desc *d, double *Q_slow,
+                                           const double *Q_fast);
+/* update!() of the LSRK methods on the handle's real elements (LowStorageRungeKuttaMethod.jl:
+ * 146-166): Q += rkb_dt * dQ; dQ *= rka_next */
+int cmdg_lsrk_update(cmdg_handle h, double *dQ, double *Q, double rka_next, double rkb_dt);
+/* dostep!(Qvec, split::SplitExplicitLSRK2nSolver, ...) (SplitExplicitMethod.jl:88-190): one
+ * slow step of size dt_slow whose every stage sub-steps the fast model with full LSRK steps
+ * of at most dt_fast.  dQ_slow / dQ_fast are the LSRK tendency accumulators (zero before the
+ * first step), dQ2fast a scratch of the slow state's shape.  coupled == 0 runs the two
+ * models side by side without the exchange (the `Uncoupled` variant of the test). */
+int cmdg_split_explicit_step(cmdg_handle slow, cmdg_handle fast,
+                             const cmdg_ocean_coupling_desc *d, int32_t coupled, double *Q_slow,
+                             double *dQ_slow, double *dQ2fast, double *Q_fast, double *dQ_fast,
+                             double t, double dt_slow, double dt_fast, int32_t nstages,
+                             const double *rka, const double *rkb, const double *rkc);
 
 /* ---- measurement --------------------------------------------------------------- */
 enum {

@@ -63,6 +63,8 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.orc_advdiff_new.restype = C.POINTER(_Physics)
         _LIB.orc_advdiff_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _LIB.orc_sw_new.restype = C.POINTER(_Physics)
+        _LIB.orc_sw_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _LIB.orc_pgrad_new.restype = C.POINTER(_Physics)
         _LIB.orc_pgrad_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         if hasattr(_LIB, "orc_ocean_new"):
@@ -122,7 +124,7 @@ class OraclePhysics:
         self._ip = np.ascontiguousarray(ip, dtype=np.int32)
         self._dp = np.ascontiguousarray(dp, dtype=np.float64)
         ctor = {1: "orc_advdiff_new", 2: "orc_atmos_new", 3: "orc_ocean_new",
-                4: "orc_pgrad_new"}[law.physics_id]
+                4: "orc_pgrad_new", 5: "orc_sw_new"}[law.physics_id]
         self.c = getattr(lib(), ctor)(_p(self._ip), _p(self._dp), int(nf_first))
         ph = self.c.contents
         self.ns, self.naux, self.ngrad = ph.ns, ph.naux, ph.ngrad
@@ -527,10 +529,35 @@ def hydrostatic_boussinesq_hooks(dg, vert_filter, exp_filter):
     dg._ocean_keep = SimpleNamespace(ilaw=ilaw, rlaw=rlaw)
     nv = grid.topology.stacksize
 
+    vlaw = integral_fields_law([(0, 0), (0, 1)], [1.0, 1.0], [0, 1], [0, 1], [0, 1], 4, 2)
+    dg._ocean_keep.vlaw = vlaw
+    dg.integral_aux = np.zeros((grid.nelem, 2, grid.Np))      # VerticalIntegralModel: int_x[2]
+
+    def integrate_velocity(X):
+        """update_auxiliary_state!(integral_model, ...) (VerticalIntegralModel.jl:60-81):
+        A.int_x = (x.u[1], x.u[2]) then the upward column integral; returns the value at the
+        top of every stack, shape (nhorz, 2, Nqh)."""
+        ia = dg.integral_aux
+        ia[:, 0, :], ia[:, 1, :] = X[:, 0, :], X[:, 1, :]
+        indefinite_stack_integral(vlaw, dg.og, X, ia)
+        Nqh = grid.Nq[0] * grid.Nq[1]
+        return ia.reshape(grid.nelem // nv, nv, 2, grid.Nq[2], Nqh)[:, -1, :, -1, :]
+
+    dg.integrate_velocity = integrate_velocity
+
     def pre(dgm, Q, t, which):
         if which == "real":
             apply_filter(Q, _T((1, 2)), grid, vert_filter, direction=VERTICAL)
             apply_filter(Q, _T((4,)), grid, exp_filter, direction=VERTICAL)
+        if getattr(law, "coupled", False) and which == "real":
+            # compute_flow_deviation!(dg, ::HBModel, ::Coupled, Q, t)
+            # (HydrostaticBoussinesqCoupling.jl:43-85): u_d = u - (vertical mean of u)
+            top = integrate_velocity(Q)
+            Nqh = grid.Nq[0] * grid.Nq[1]
+            A5 = dgm.state_auxiliary.reshape(grid.nelem // nv, nv, 8, grid.Nq[2], Nqh)
+            Q5 = Q.reshape(grid.nelem // nv, nv, 4, grid.Nq[2], Nqh)
+            for c in (0, 1):
+                A5[:, :, 4 + c] = Q5[:, :, c] - (top[:, c] / law.problem.H)[:, None, None, :]
 
     def post(dgm, Q, t, which):
         A, D = dgm.state_auxiliary, dgm.state_gradient_flux
@@ -548,6 +575,65 @@ def hydrostatic_boussinesq_hooks(dg, vert_filter, exp_filter):
 
     dg.update_auxiliary_state_hook = pre
     dg.update_auxiliary_state_gradient_hook = post
+
+
+# ---- SplitExplicitSolver (src/Numerics/ODESolvers/SplitExplicitMethod.jl:70-177) ----------
+class SplitExplicitOracle:
+    """The split-explicit barotropic / baroclinic stepper restated: slow 3-D HBModel and fast
+    2-D ShallowWaterModel (on the one-layer extrusion of the 2-D grid), both LSRK54, with the
+    coupling functions of src/Ocean/SplitExplicit/Communication.jl.  ``dg3`` must carry
+    ``hydrostatic_boussinesq_hooks`` (for ``integrate_velocity``)."""
+
+    def __init__(self, dg3, dg2, Q3, Q2, dt_slow, dt_fast):
+        self.dg3, self.dg2, self.dt, self.dt_fast = dg3, dg2, float(dt_slow), float(dt_fast)
+        self.dQ3 = np.zeros_like(Q3)
+        self.dQ2fast = np.full_like(Q3, -0.0)
+        self.dQ2 = np.zeros_like(Q2)
+        self.coupled = bool(dg3.law.coupled)
+        g3, g2 = dg3.grid, dg2.grid
+        self.nv = g3.topology.stacksize
+        self.nh = g3.nelem // self.nv
+        self.Nqh = g3.Nq[0] * g3.Nq[1]
+        self.Nqk3, self.Nqk2 = g3.Nq[2], g2.Nq[2]
+        self.H = dg3.law.problem.H
+
+    # views: 3-D arrays as (nh, nv, nvar, Nqk, Nqh); extruded 2-D arrays as (nh, nvar, Nqk2, Nqh)
+    def _v3(self, a):
+        return a.reshape(self.nh, self.nv, a.shape[1], self.Nqk3, self.Nqh)
+
+    def _v2(self, a):
+        return a.reshape(self.nh, a.shape[1], self.Nqk2, self.Nqh)
+
+    def dostep(self, Q3, Q2, time):
+        dg3, dg2, H = self.dg3, self.dg2, self.H
+        A3, A2 = dg3.state_auxiliary, dg2.state_auxiliary
+        ns = len(RKA)
+        for s in range(ns):
+            ts = time + RKC[s] * self.dt
+            if self.coupled:                       # initialize_states!: A.dG_u = -0
+                A3[:, 6:8, :] = -0.0
+            dg3(self.dQ2fast, Q3, ts, 1.0, 0.0)    # slow.rhs!(dQ2fast, ...; increment = false)
+            if self.coupled:                       # tendency_from_slow_to_fast!
+                top = dg3.integrate_velocity(self.dQ2fast)            # (nh, 2, Nqh)
+                self._v2(A2)[:, 1:3] = top[:, :, None, :]             # G_U = int du
+                self._v3(A3)[:, :, 6:8] -= (top / H)[:, None, :, None, :]
+            dg3(self.dQ3, Q3, ts, 1.0, 1.0)        # slow.rhs!(dQslow, ...; increment = true)
+            gamma = (1 - RKC[s]) if s == ns - 1 else (RKC[s + 1] - RKC[s])
+            nsub = int(np.ceil(gamma * self.dt / self.dt_fast)) if self.dt_fast > 0 else 1
+            fdt = gamma * self.dt / nsub
+            for sub in range(nsub):
+                ft = ts + sub * fdt
+                lsrk_step(dg2, Q2, self.dQ2, ft, fdt, RKA, RKB, RKC)
+            n = dg3.grid.nreal * Q3.shape[1] * Q3.shape[2]
+            lib().orc_lsrk_update(_p(self.dQ3), _p(Q3), C.c_double(RKA[(s + 1) % ns]),
+                                  C.c_double(RKB[s]), C.c_double(self.dt), C.c_int64(n))
+            if self.coupled:                       # reconcile_from_fast_to_slow!
+                top = dg3.integrate_velocity(Q3)
+                U = self._v2(Q2)[:, 1:3, 0, :]                         # (nh, 2, Nqh)
+                du = 1 / H * (U - top)
+                self._v2(A2)[:, 3:5] = du[:, :, None, :]
+                self._v3(Q3)[:, :, 0:2] += du[:, None, :, None, :]
+                self._v3(Q3)[:, :, 2] = self._v2(Q2)[:, 0, 0, :][:, None, None, :]
 
 
 # ---- element filters (filter_oracle.c) --------------------------------------------------

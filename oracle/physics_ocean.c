@@ -11,6 +11,7 @@
  * test/Ocean/refvals/3D_hydrostatic_spindown_refvals.jl (StateCheck, 12 digits).
  *
  * Parameter block:
+ *   iparam[3]=coupling (0 Uncoupled, 1 Coupled: src/Ocean/SplitExplicit/HydrostaticBoussinesqCoupling.jl)
  *   iparam[0]=momentum advection (NonLinearAdvectionTerm) [1]=tracer advection
  *   [2]=Coriolis: 0 SimpleBox{Fixed} (f = -0), 1 SimpleBox{Rotating} (f = f_o), 2 beta plane
  *   [6]=nbc [7..13]=bc of tag 1..7: velocity kind + 8 * temperature kind, velocity kinds
@@ -26,11 +27,11 @@
 #include "dg_oracle.h"
 
 typedef struct {
-    int madv, tadv, cor, nbc, bc[8];
+    int madv, tadv, cor, coupled, nbc, bc[8];
     double grav, ch, cz, aT, nuh, nuz, kh, kz, kc, fo, beta, tau_o, rho_o, Ly, lam_r, thE;
 } ocean_t;
 enum { U = 0, V = 1, ETA = 2, TH = 3 };                 /* prognostic */
-enum { AY = 0, AW = 1, APKIN = 2, AWZ0 = 3 };           /* auxiliary */
+enum { AY = 0, AW = 1, APKIN = 2, AWZ0 = 3, AUD = 4 };  /* auxiliary (u_d at 4, 5) */
 enum { GDIVH = 0, GNU = 1, GKAPPA = 7 };                /* gradient flux */
 enum { BV_NOSLIP = 1, BV_FREESLIP = 2, BV_PENETRABLE = 3, BV_STRESS = 4, BV_PEN_STRESS = 5 };
 
@@ -42,8 +43,8 @@ static void oc_flux1(const void *p_, double *F, const double *Q, const double *a
     const double ge = m->grav * Q[ETA], gp = m->grav * aux[APKIN];
     for (int c = 0; c < 2; ++c)
         for (int d = 0; d < 3; ++d) {
-            F[d + 3 * c] += ge * Ih[d][c]; /* hydrostatic_pressure! */
-            F[d + 3 * c] += gp * Ih[d][c]; /* kinematic_pressure! */
+            if (!m->coupled) F[d + 3 * c] += ge * Ih[d][c]; /* hydrostatic_pressure! (Uncoupled) */
+            F[d + 3 * c] += gp * Ih[d][c];                  /* kinematic_pressure! */
         }
     const double v[3] = {Q[U], Q[V], aux[AW]};
     if (m->madv)
@@ -74,8 +75,13 @@ static void oc_source(const void *p_, double *S, const double *Q, const double *
     (void)gf; (void)t; (void)dir;
     S[ETA] += aux[AWZ0];
     const double f = coriolis(m, aux[AY]);
-    S[U] -= -f * Q[V];
-    S[V] -= f * Q[U];
+    if (m->coupled) { /* coriolis_force!(::Coupled): the velocity deviation from the vertical mean */
+        S[U] -= -f * aux[AUD + 1];
+        S[V] -= f * aux[AUD];
+    } else {
+        S[U] -= -f * Q[V];
+        S[V] -= f * Q[U];
+    }
     /* forcing: noforcing(args...) = 0 for every variable */
     S[U] += 0;
     S[V] += 0;
@@ -85,10 +91,15 @@ static void oc_source(const void *p_, double *S, const double *Q, const double *
 
 static void oc_gradarg(const void *p_, double *G, const double *Q, const double *aux, double t)
 {
-    (void)p_; (void)aux; (void)t;
+    const ocean_t *m = (const ocean_t *)p_;
+    (void)t;
     G[4] = Q[TH]; /* Gradient vars: grad u[2], grad u_d[2] (untouched when uncoupled), grad theta */
     G[0] = Q[U];
     G[1] = Q[V];
+    if (m->coupled) { /* velocity_gradient_argument!(::Coupled) */
+        G[2] = aux[AUD];
+        G[3] = aux[AUD + 1];
+    }
 }
 
 static void oc_gradflux(const void *p_, double *D, const double *g, const double *Q, const double *aux,
@@ -99,7 +110,11 @@ static void oc_gradflux(const void *p_, double *D, const double *g, const double
     D[GDIVH] = g[0 + 3 * 0] + g[1 + 3 * 1];
     const double nu[3] = {m->nuh, m->nuh, m->nuz};
     for (int c = 0; c < 2; ++c)
-        for (int d = 0; d < 3; ++d) D[GNU + d + 3 * c] = -nu[d] * g[d + 3 * c];
+        for (int d = 0; d < 3; ++d) {
+            /* Coupled: horizontal derivatives of u_d, vertical derivative of u */
+            const double gu = (m->coupled && d < 2) ? g[d + 3 * (2 + c)] : g[d + 3 * c];
+            D[GNU + d + 3 * c] = -nu[d] * gu;
+        }
     const double dthdz = g[2 + 3 * 4];
     const double kap[3] = {m->kh, m->kh, dthdz < 0 ? m->kc : m->kz};
     for (int d = 0; d < 3; ++d) D[GKAPPA + d] = -kap[d] * g[d + 3 * 4];
@@ -213,7 +228,7 @@ orc_physics *orc_ocean_new(const int *ip, const double *dp, int nf_first)
 {
     orc_physics *ph = (orc_physics *)calloc(1, sizeof(orc_physics));
     ocean_t *m = (ocean_t *)calloc(1, sizeof(ocean_t));
-    m->madv = ip[0]; m->tadv = ip[1]; m->cor = ip[2]; m->nbc = ip[6];
+    m->madv = ip[0]; m->tadv = ip[1]; m->cor = ip[2]; m->coupled = ip[3]; m->nbc = ip[6];
     for (int i = 0; i < 7; ++i) m->bc[i] = ip[7 + i];
     m->grav = dp[0]; m->ch = dp[1]; m->cz = dp[2]; m->aT = dp[3]; m->nuh = dp[4]; m->nuz = dp[5];
     m->kh = dp[6]; m->kz = dp[7]; m->kc = dp[8]; m->fo = dp[9]; m->beta = dp[10];

@@ -245,3 +245,77 @@ def heat_eqn_setup(level=1, direction=0, N=4, rank=0, size=1):
     dt = 1 / (Ne * N ** 2) ** 2
     nsteps = int(np.ceil(0.01 / dt))
     return law, grid, 0.01 / nsteps, nsteps
+
+
+def split_explicit_setup(coupled=True, Nx=5, Ny=5, Nz=8, N=4):
+    """test/Ocean/SplitExplicit/hydrostatic_spindown.jl:3-140 (SplitExplicitSolver variant):
+    SimpleBox 1e6 x 1e6 x 400 m, 3-D HBModel (c_h = 1, alpha_T = kappa = 0, default Coriolis
+    parameters but a Fixed box, so f = -0) + 2-D ShallowWaterModel (ConstantViscosity(nu_h),
+    c = 1); periodic in x and y; the barotropic model on the one-layer extrusion of the 2-D grid."""
+    O = cm.ocean
+    Lx, Ly, H = 1e6, 1e6, 400.0
+    problem = O.SimpleBox(Lx, Ly, H)
+    law3 = O.HydrostaticBoussinesqModel(problem, c_h=1.0, alpha_T=0.0, kappa_h=0.0, kappa_z=0.0,
+                                        coupled=coupled)
+    law2 = O.ShallowWaterModel(problem, law3.nu_h, advection=False, coupled=coupled, c=1.0)
+    x, y = np.linspace(0.0, Lx, Nx + 1), np.linspace(0.0, Ly, Ny + 1)
+    topl = M.StackedBrickTopology([x, y, np.linspace(-H, 0.0, Nz + 1)],
+                                  periodicity=(True, True, False), boundary=((0, 0), (0, 0), (1, 2)))
+    grid3 = M.DiscontinuousSpectralElementGrid(topl, N)
+    grid2 = O.extruded_barotropic_grid(x, y, N)
+    return law3, grid3, law2, grid2
+
+
+def split_explicit_schedule(dt_slow, tout=3 * 3600.0, timeend=86400.0):
+    """run_split_explicit (test/Ocean/SplitExplicit/hydrostatic_spindown.jl:60-75): the slow
+    step is shortened so that an integer number of steps reaches the output interval."""
+    nout = int(np.ceil(tout / dt_slow))
+    dt = tout / nout
+    return dt, int(round(timeend / dt))
+
+
+def statecheck(a):
+    """``scstats`` (src/Diagnostics/Debug/StateCheck.jl:231-283)."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    m = a.mean()
+    return a.min(), a.max(), m, np.sqrt(((a - m) ** 2).sum() / (a.size - 1))
+
+
+def split_explicit_fields(Q3, A3, Q2, A2, grid2):
+    """The twenty rows of the reference table; the 2-D arrays are read on the k = 0 plane of the
+    one-layer extrusion (the reference's 2-D grid has exactly those nodes)."""
+    Nqh = grid2.Nq[0] * grid2.Nq[1]
+    q0 = np.asarray(Q2).reshape(grid2.nelem, Q2.shape[1], grid2.Nq[2], Nqh)[:grid2.nreal, :, 0, :]
+    a0 = np.asarray(A2).reshape(grid2.nelem, A2.shape[1], grid2.Nq[2], Nqh)[:grid2.nreal, :, 0, :]
+    f = {}
+    for i, n in enumerate(("u[1]", "u[2]", "η", "θ")):
+        f[("3D state", n)] = Q3[:, i]
+    for i, n in enumerate(("y", "w", "pkin", "wz0", "uᵈ[1]", "uᵈ[2]", "ΔGᵘ[1]", "ΔGᵘ[2]")):
+        f[("3D aux", n)] = A3[:, i]
+    for i, n in enumerate(("η", "U[1]", "U[2]")):
+        f[("2D state", n)] = q0[:, i]
+    for i, n in enumerate(("y", "Gᵁ[1]", "Gᵁ[2]", "Δu[1]", "Δu[2]")):
+        f[("2D aux", n)] = a0[:, i]
+    return f
+
+
+def check_split_explicit_table(table, parr, fields, slack=2.0):
+    """Every statistic the reference checks (precision > 0 in ``parr``), to ``slack`` units of
+    its stated digit; exact zeros must be exact.  Returns the worst relative deviation."""
+    worst = 0.0
+    for row, prow in zip(table, parr):
+        key = (row[0], row[1])
+        assert key == (prow[0], prow[1])
+        got = statecheck(fields[key])
+        for j in range(4):
+            p = int(prow[2 + j])
+            if p == 0:
+                continue
+            ref = row[2 + j]
+            if ref == 0:
+                assert got[j] == 0, (key, j, got[j])
+                continue
+            rel = abs(got[j] - ref) / abs(ref)
+            worst = max(worst, rel * 10.0 ** p)
+            assert rel <= slack * 10.0 ** (-p), (key, j, got[j], ref, rel)
+    return worst

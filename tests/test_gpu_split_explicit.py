@@ -1,0 +1,157 @@
+"""Split-explicit barotropic / baroclinic ocean stepper on the GPU (BASELINE config 5):
+the exchange functions and whole slow steps against the oracle, and the reference's five
+regression runs (test/Ocean/SplitExplicit/test_spindown_long.jl + StateCheck tables) end to end
+on the device through ``cmdg_split_explicit_step``.  ``-m gpu``."""
+import numpy as np
+import pytest
+
+from helpers import (check_split_explicit_table, rel_linf, split_explicit_fields,
+                     split_explicit_schedule, split_explicit_setup)
+from test_split_explicit_oracle import GOLD, relaxed
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "no HIP device: the product path has no CPU fallback"
+    return t
+
+
+def _gpu(torch, a):
+    x = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    torch.cuda.synchronize()
+    return x
+
+
+def _device_pair(cm, torch, law3, g3, law2, g2):
+    O = cm.ocean
+    dg3 = cm.dgmodel.DGModel(law3, g3)
+    keep = O.install_hydrostatic_boussinesq_hooks(dg3)
+    dg2 = cm.dgmodel.DGModel(law2, g2, numerical_flux_first_order=cm.balancelaws.CentralNumericalFluxFirstOrder)
+    return dg3, dg2, keep
+
+
+def _oracle_pair(cm, oracle, law3, g3, law2, g2):
+    F = cm.mesh.filters
+    o3 = oracle.OracleDGModel(law3, g3)
+    oracle.hydrostatic_boussinesq_hooks(o3, F.CutoffFilter(g3, g3.N[-1] - 1),
+                                        F.ExponentialFilter(g3, 1, 8))
+    o2 = oracle.OracleDGModel(law2, g2, nf_first=1)
+    return o3, o2
+
+
+def _close(dg3, dg2, keep):
+    dg3.set_rhs_hooks()
+    for f in keep:
+        f.close()
+    dg3.close()
+    dg2.close()
+
+
+def _scaled(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_exchange_functions_match_oracle(cm, oracle, torch):
+    law3, g3, law2, g2 = split_explicit_setup(True, Nx=3, Ny=2, Nz=3)
+    o3, o2 = _oracle_pair(cm, oracle, law3, g3, law2, g2)
+    dg3, dg2, keep = _device_pair(cm, torch, law3, g3, law2, g2)
+    rng = np.random.default_rng(7)
+    Q3 = law3.init_state_prognostic(g3, o3.state_auxiliary, 1800.0)
+    Q3[:, 0:2] += 0.05 * rng.standard_normal(Q3[:, 0:2].shape)
+    Q2 = law2.init_state_prognostic(g2, o2.state_auxiliary, 1800.0)
+    Q2[:, 1:3] += 5.0 * rng.standard_normal((g2.nelem, 2, 1, g2.Nq[0] * g2.Nq[1])).repeat(
+        g2.Nq[2], axis=2).reshape(g2.nelem, 2, -1)
+    dQ = rng.standard_normal(Q3.shape) * 1e-6
+    Q3g, Q2g = _gpu(torch, Q3), _gpu(torch, Q2)
+    se_o = oracle.SplitExplicitOracle(o3, o2, Q3, Q2, 1800.0, 300.0)
+    se = cm.ocean.SplitExplicitLSRK2nSolver(dg3, dg2, Q3g, Q2g, 1800.0, 300.0)
+    # initialize_states! + tendency_from_slow_to_fast!
+    o3.state_auxiliary[:, 6:8] = 1.0
+    dg3.state_auxiliary[:, 6:8] = 1.0
+    torch.cuda.synchronize()
+    se.initialize_states()
+    se.tendency_from_slow_to_fast(_gpu(torch, dQ))
+    dg3.synchronize()
+    o3.state_auxiliary[:, 6:8] = -0.0
+    top = o3.integrate_velocity(dQ)
+    se_o._v2(o2.state_auxiliary)[:, 1:3] = top[:, :, None, :]
+    se_o._v3(o3.state_auxiliary)[:, :, 6:8] -= (top / se_o.H)[:, None, :, None, :]
+    assert _scaled(dg2.state_auxiliary.cpu().numpy()[:, 1:3], o2.state_auxiliary[:, 1:3]) < TOL
+    assert _scaled(dg3.state_auxiliary.cpu().numpy()[:, 6:8], o3.state_auxiliary[:, 6:8]) < TOL
+    # reconcile_from_fast_to_slow!
+    se.reconcile_from_fast_to_slow(Q3g, Q2g)
+    dg3.synchronize()
+    top = o3.integrate_velocity(Q3)
+    du = 1 / se_o.H * (se_o._v2(Q2)[:, 1:3, 0, :] - top)
+    se_o._v2(o2.state_auxiliary)[:, 3:5] = du[:, :, None, :]
+    se_o._v3(Q3)[:, :, 0:2] += du[:, None, :, None, :]
+    se_o._v3(Q3)[:, :, 2] = se_o._v2(Q2)[:, 0, 0, :][:, None, None, :]
+    assert _scaled(dg2.state_auxiliary.cpu().numpy()[:, 3:5], o2.state_auxiliary[:, 3:5]) < TOL
+    Qn = Q3g.cpu().numpy()
+    assert _scaled(Qn[:, 0:2], Q3[:, 0:2]) < TOL
+    assert np.array_equal(Qn[:, 2], Q3[:, 2]) and np.array_equal(Qn[:, 3], Q3[:, 3])
+    # after the reconciliation the vertical mean of u is U / H
+    top = o3.integrate_velocity(Qn)
+    assert _scaled(top / se_o.H, se_o._v2(Q2)[:, 1:3, 0, :] / se_o.H) < 1e-11
+    _close(dg3, dg2, keep)
+
+
+@pytest.mark.parametrize("coupled,dt_slow", [(True, 1800.0), (True, 300.0), (False, 300.0)])
+def test_split_explicit_steps_match_oracle(cm, oracle, torch, coupled, dt_slow):
+    law3, g3, law2, g2 = split_explicit_setup(coupled, Nx=3, Ny=2, Nz=3)
+    o3, o2 = _oracle_pair(cm, oracle, law3, g3, law2, g2)
+    dg3, dg2, keep = _device_pair(cm, torch, law3, g3, law2, g2)
+    Q3 = law3.init_state_prognostic(g3, o3.state_auxiliary, 0.0)
+    Q2 = law2.init_state_prognostic(g2, o2.state_auxiliary, 0.0)
+    Q3g, Q2g = _gpu(torch, Q3), _gpu(torch, Q2)
+    se_o = oracle.SplitExplicitOracle(o3, o2, Q3, Q2, dt_slow, 300.0)
+    se = cm.ocean.SplitExplicitLSRK2nSolver(dg3, dg2, Q3g, Q2g, dt_slow, 300.0)
+    t = 0.0
+    for _ in range(3):
+        se_o.dostep(Q3, Q2, t)
+        t += dt_slow
+    se.dostep(Q3g, Q2g, 3)
+    assert se.t == t and se.steps == 3
+    A3, A2 = dg3.state_auxiliary.cpu().numpy(), dg2.state_auxiliary.cpu().numpy()
+    Qn3, Qn2 = Q3g.cpu().numpy(), Q2g.cpu().numpy()
+    for s in (0, 2):                      # u, eta (v stays at rounding level, theta is zero)
+        assert _scaled(Qn3[:, s], Q3[:, s]) < TOL, s
+    assert np.abs(Qn3[:, 1]).max() < 1e-12 and not Qn3[:, 3].any()
+    for s in (0, 1):                      # eta, U
+        assert _scaled(Qn2[:, s], Q2[:, s]) < TOL, s
+    cols3 = (1, 3, 4, 6) if coupled else (1, 3)     # w, wz0, u_d, dG_u
+    for c in cols3:
+        tol = 1e-9 if c == 6 else TOL               # dG_u: see test_split_explicit_oracle.py
+        assert _scaled(A3[:, c], o3.state_auxiliary[:, c]) < tol, c
+    if coupled:
+        assert _scaled(A2[:, 1], o2.state_auxiliary[:, 1]) < 1e-9      # G_U
+        assert _scaled(A2[:, 3], o2.state_auxiliary[:, 3]) < 1e-9      # Delta_u, a difference
+    _close(dg3, dg2, keep)
+
+
+@pytest.mark.parametrize("name,coupled,dt_slow", [
+    ("uncoupled", False, 300.0), ("coupled", True, 300.0), ("thirty_minutes", True, 1800.0),
+    ("sixty_minutes", True, 3600.0), ("ninety_minutes", True, 5400.0)])
+def test_device_split_explicit_reproduces_reference_tables(cm, oracle, torch, name, coupled,
+                                                           dt_slow):
+    """test_spindown_long.jl: one simulated day, all five configurations, checked against the
+    reference's StateCheck rows and the analytic-solution bound of run_split_explicit."""
+    law3, g3, law2, g2 = split_explicit_setup(coupled)
+    dg3, dg2, keep = _device_pair(cm, torch, law3, g3, law2, g2)
+    Q3g, Q2g = dg3.init_ode_state(0.0), dg2.init_ode_state(0.0)
+    dt, nsteps = split_explicit_schedule(dt_slow)
+    se = cm.ocean.SplitExplicitLSRK2nSolver(dg3, dg2, Q3g, Q2g, dt, 300.0)
+    se.dostep(Q3g, Q2g, nsteps)
+    Q3, Q2 = Q3g.cpu().numpy(), Q2g.cpu().numpy()
+    A3, A2 = dg3.state_auxiliary.cpu().numpy(), dg2.state_auxiliary.cpu().numpy()
+    fields = split_explicit_fields(Q3, A3, Q2, A2, g2)
+    check_split_explicit_table(GOLD[name], relaxed(GOLD["parr"]), fields, slack=3.0)
+    for law, g, Q, A in ((law3, g3, Q3, A3), (law2, g2, Q2, A2)):
+        Qe = law.init_state_prognostic(g, A, 86400.0)
+        err = np.sqrt(oracle.weighted_norm2_local(g, Q, Qe) / oracle.weighted_norm2_local(g, Qe))
+        assert err < 0.005
+    _close(dg3, dg2, keep)
