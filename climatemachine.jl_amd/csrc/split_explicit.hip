@@ -1,6 +1,6 @@
 // Split-explicit barotropic / baroclinic ocean stepper: the exchange functions of
 // src/Ocean/SplitExplicit/Communication.jl and dostep! of
-// src/Numerics/ODESolvers/SplitExplicitMethod.jl:88-190 over two engines (slow 3-D
+// src/Numerics/ODESolvers/SplitExplicitMethod.jl:70-177 over two engines (slow 3-D
 // HydrostaticBoussinesqModel, fast ShallowWaterModel on the one-layer extrusion of the 2-D grid).
 // Everything is enqueued on the slow engine's compute stream except the fast model's own
 // sub-steps; the two streams are ordered with events, the host never waits.

@@ -232,9 +232,9 @@ def install_hydrostatic_boussinesq_hooks(dg, vert_filter=None, exp_filter=None):
     return fu, ft
 
 
-class SplitExplicitLSRK2nSolver:
-    """``SplitExplicitLSRK2nSolver(slow_solver, fast_solver)`` of
-    src/Numerics/ODESolvers/SplitExplicitMethod.jl:21-86 over two device operators: ``dg_slow``
+class SplitExplicitSolver:
+    """``SplitExplicitSolver(slow_solver, fast_solver)`` of
+    src/Numerics/ODESolvers/SplitExplicitMethod.jl:30-68 over two device operators: ``dg_slow``
     the 3-D HydrostaticBoussinesqModel (with its hooks installed), ``dg_fast`` the
     ShallowWaterModel on ``extruded_barotropic_grid``.  ``dostep`` advances both states in
     place by ``nsteps`` slow steps; the coupling runs when the slow law is ``Coupled``."""

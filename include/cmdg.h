@@ -282,7 +282,7 @@ typedef struct cmdg_rhs_hooks {
 /* hooks == NULL clears them.  Filters must outlive their use. */
 int cmdg_set_rhs_hooks(cmdg_handle h, const cmdg_rhs_hooks *hooks);
 
-/* ---- split-explicit ocean (src/Numerics/ODESolvers/SplitExplicitMethod.jl:1-190 and
+/* ---- split-explicit ocean (src/Numerics/ODESolvers/SplitExplicitMethod.jl:1-177 and
  * src/Ocean/SplitExplicit/Communication.jl) --------------------------------------------
  * `slow` is the 3-D HydrostaticBoussinesqModel handle (Coupled), `fast` the ShallowWaterModel
  * handle on the one-layer extrusion of the 2-D grid; both share the horizontal element order
@@ -313,7 +313,7 @@ int cmdg_ocean_reconcile_from_fast_to_slow(cmdg_handle slow, cmdg_handle fast,
 /* update!() of the LSRK methods on the handle's real elements (LowStorageRungeKuttaMethod.jl:
  * 146-166): Q += rkb_dt * dQ; dQ *= rka_next */
 int cmdg_lsrk_update(cmdg_handle h, double *dQ, double *Q, double rka_next, double rkb_dt);
-/* dostep!(Qvec, split::SplitExplicitLSRK2nSolver, ...) (SplitExplicitMethod.jl:88-190): one
+/* dostep!(Qslow, split::SplitExplicitSolver, param, time) (SplitExplicitMethod.jl:70-177): one
  * slow step of size dt_slow whose every stage sub-steps the fast model with full LSRK steps
  * of at most dt_fast.  dQ_slow / dQ_fast are the LSRK tendency accumulators (zero before the
  * first step), dQ2fast a scratch of the slow state's shape.  coupled == 0 runs the two

@@ -32,7 +32,7 @@ dg3 = cm.dgmodel.DGModel(law3, g3)
 keep = O.install_hydrostatic_boussinesq_hooks(dg3)
 dg2 = cm.dgmodel.DGModel(law2, g2, numerical_flux_first_order=cm.balancelaws.CentralNumericalFluxFirstOrder)
 Q3, Q2 = dg3.init_ode_state(0.0), dg2.init_ode_state(0.0)
-se = O.SplitExplicitLSRK2nSolver(dg3, dg2, Q3, Q2, dt_slow, dt_fast)
+se = O.SplitExplicitSolver(dg3, dg2, Q3, Q2, dt_slow, dt_fast)
 se.dostep(Q3, Q2, 2)
 torch.cuda.synchronize()
 t0 = time.perf_counter()

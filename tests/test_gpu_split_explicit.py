@@ -68,7 +68,7 @@ def test_exchange_functions_match_oracle(cm, oracle, torch):
     dQ = rng.standard_normal(Q3.shape) * 1e-6
     Q3g, Q2g = _gpu(torch, Q3), _gpu(torch, Q2)
     se_o = oracle.SplitExplicitOracle(o3, o2, Q3, Q2, 1800.0, 300.0)
-    se = cm.ocean.SplitExplicitLSRK2nSolver(dg3, dg2, Q3g, Q2g, 1800.0, 300.0)
+    se = cm.ocean.SplitExplicitSolver(dg3, dg2, Q3g, Q2g, 1800.0, 300.0)
     # initialize_states! + tendency_from_slow_to_fast!
     o3.state_auxiliary[:, 6:8] = 1.0
     dg3.state_auxiliary[:, 6:8] = 1.0
@@ -109,7 +109,7 @@ def test_split_explicit_steps_match_oracle(cm, oracle, torch, coupled, dt_slow):
     Q2 = law2.init_state_prognostic(g2, o2.state_auxiliary, 0.0)
     Q3g, Q2g = _gpu(torch, Q3), _gpu(torch, Q2)
     se_o = oracle.SplitExplicitOracle(o3, o2, Q3, Q2, dt_slow, 300.0)
-    se = cm.ocean.SplitExplicitLSRK2nSolver(dg3, dg2, Q3g, Q2g, dt_slow, 300.0)
+    se = cm.ocean.SplitExplicitSolver(dg3, dg2, Q3g, Q2g, dt_slow, 300.0)
     t = 0.0
     for _ in range(3):
         se_o.dostep(Q3, Q2, t)
@@ -144,7 +144,7 @@ def test_device_split_explicit_reproduces_reference_tables(cm, oracle, torch, na
     dg3, dg2, keep = _device_pair(cm, torch, law3, g3, law2, g2)
     Q3g, Q2g = dg3.init_ode_state(0.0), dg2.init_ode_state(0.0)
     dt, nsteps = split_explicit_schedule(dt_slow)
-    se = cm.ocean.SplitExplicitLSRK2nSolver(dg3, dg2, Q3g, Q2g, dt, 300.0)
+    se = cm.ocean.SplitExplicitSolver(dg3, dg2, Q3g, Q2g, dt, 300.0)
     se.dostep(Q3g, Q2g, nsteps)
     Q3, Q2 = Q3g.cpu().numpy(), Q2g.cpu().numpy()
     A3, A2 = dg3.state_auxiliary.cpu().numpy(), dg2.state_auxiliary.cpu().numpy()
