@@ -1,10 +1,11 @@
 """Polynomial orders other than N = 4 (every kernel is templated on Nq = N + 1): the HIP path
-against the oracle for N = 1..7 (advection-diffusion), N = 2, 3, 5 (dry atmosphere), and the
+against the oracle for N = 1..7 (advection-diffusion), N = 2, 3, 5, 6 (dry atmosphere, with
+hyperdiffusion and with SmagorinskyLilly -- N = 6 is the order of BASELINE configs[3]), and the
 reference's filter / integral tests at their own orders (N = 3).  ``-m gpu``."""
 import numpy as np
 import pytest
 
-from helpers import held_suarez_setup, pseudo1d_setup, rel_linf
+from helpers import held_suarez_setup, pseudo1d_setup, rel_linf, rising_bubble_setup
 from test_filters_oracle import _filter_test_state
 from test_integrals_oracle import _approx, integral_test_aux, integral_test_grid
 
@@ -51,7 +52,7 @@ def test_advdiff_orders_match_oracle(cm, oracle, torch, N):
     dg.close()
 
 
-@pytest.mark.parametrize("N", [2, 3, 5])
+@pytest.mark.parametrize("N", [2, 3, 5, 6])
 def test_held_suarez_orders_match_oracle(cm, oracle, torch, N):
     law, grid, d, dd = held_suarez_setup(n_horz=2, n_vert=2, N=N)
     odg = oracle.OracleDGModel(law, grid, direction=d, diffusion_direction=dd)
@@ -71,6 +72,37 @@ def test_held_suarez_orders_match_oracle(cm, oracle, torch, N):
     for kind in (0, 1):
         o = oracle.courant(kind, odg, Q0, 1.0, 0.0, 0)
         assert abs(dg.courant(kind, Qg, 1.0, 0.0, 0) - o) <= 1e-12 * abs(o)
+    dg.close()
+
+
+def test_smagorinsky_order_six_matches_oracle(cm, oracle, torch):
+    """N = 6 with the SmagorinskyLilly closure: one element's working set is 78 KB of LDS in
+    k_tendency (more than the 64 KB a work-group gets on older parts)."""
+    law, grid = rising_bubble_setup(nx=2, ny=2, nz=3, N=6)
+    odg = oracle.OracleDGModel(law, grid)
+    dg = cm.dgmodel.DGModel(law, grid)
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    rng = np.random.default_rng(6)
+    Q0[:, 1:4] += Q0[:, 0:1] * 3.0 * rng.standard_normal(Q0[:, 1:4].shape)
+    To = np.zeros_like(Q0)
+    odg(To, Q0.copy(), 0.0, 1.0, 0.0)
+    Tg = _gpu(torch, np.zeros_like(Q0))
+    dg(Tg, _gpu(torch, Q0), 0.0, 1.0, 0.0)
+    Tn = Tg.cpu().numpy()
+    for s in range(5):
+        assert rel_linf(Tn[:, s], To[:, s]) < TOL, s
+    gfg = dg.state_gradient_flux.cpu().numpy()
+    for s in range(law.ngradflux):
+        sc = max(np.abs(odg.state_gradient_flux[:, s]).max(), 1e-300)
+        assert np.abs(gfg[:, s] - odg.state_gradient_flux[:, s]).max() / sc < TOL, s
+    Qo, dQo = Q0.copy(), np.zeros_like(Q0)
+    for i in range(2):
+        oracle.lsrk54_step(odg, Qo, dQo, i * 0.02, 0.02)
+    Q = _gpu(torch, Q0)
+    dQ = torch.zeros_like(Q)
+    dg.lsrk_run(Q, dQ, 0.0, 0.02, 2, oracle.RKA, oracle.RKB, oracle.RKC)
+    dg.synchronize()
+    assert rel_linf(Q.cpu().numpy(), Qo) < 1e-11
     dg.close()
 
 
