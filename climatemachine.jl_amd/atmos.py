@@ -30,7 +30,7 @@ from .mesh import grids as G
 
 __all__ = ["PlanetParameters", "DryAtmosModel", "IsentropicVortexSetup", "HeldSuarezSetup",
            "DecayingTemperatureProfile", "DryAdiabaticProfile", "RisingBubbleSetup",
-           "CourantTestSetup"]
+           "CourantTestSetup", "MMSSetup"]
 
 
 class PlanetParameters:
@@ -156,6 +156,24 @@ class IsentropicVortexSetup:
         return rho, [rho * u[0], rho * u[1], rho * u[2]], rhoe
 
 
+class MMSSetup:
+    """``mms3_init_state!`` of test/Numerics/DGMethods/compressible_Navier_Stokes/
+    mms_bc_atmos.jl:88-97: the manufactured solution (generating script mms_solution.jl:10-25)
+    ``rho = c g + 3, rho u = rho (c g, c g, c h), rho e = c g + 100`` with ``c = cos(pi t)``,
+    ``g = sin(pi x) cos(pi y) cos(pi z)``, ``h = sin(pi x) cos(pi y) sin(pi z)``."""
+
+    def __init__(self, ps):
+        self.ps = ps
+
+    def __call__(self, law, aux, coord, t):
+        x, y, z = coord
+        c = np.cos(np.pi * t)
+        g = np.sin(np.pi * x) * np.cos(np.pi * y) * np.cos(np.pi * z)
+        h = np.sin(np.pi * x) * np.cos(np.pi * y) * np.sin(np.pi * z)
+        rho = g * c + 3
+        return rho, [rho * g * c, rho * g * c, rho * h * c], g * c + 100
+
+
 class CourantTestSetup:
     """``initialcondition!`` of test/Numerics/DGMethods/courant.jl:31-60: isothermal air at
     ``T_inf``, ``p_inf`` moving with ``u = 150 x (1, 1, 0)``; the potential energy passed to
@@ -217,8 +235,10 @@ class HeldSuarezSetup:
 
 
 ORIENT_NONE, ORIENT_FLAT, ORIENT_SPHERICAL = 0, 1, 2
-SRC_GRAVITY, SRC_CORIOLIS, SRC_HELD_SUAREZ = 1, 2, 4
-BC_NONE, BC_ATMOS_DEFAULT = 0, 1
+SRC_GRAVITY, SRC_CORIOLIS, SRC_HELD_SUAREZ, SRC_MMS = 1, 2, 4, 8
+# AtmosBC() default (Impenetrable(FreeSlip), Insulating); InitStateBC (bc_initstate.jl) with the
+# manufactured solution of MMSSetup
+BC_NONE, BC_ATMOS_DEFAULT, BC_INIT_STATE_MMS = 0, 1, 2
 
 
 class DryAtmosModel:
@@ -230,7 +250,11 @@ class DryAtmosModel:
     def __init__(self, init_state, orientation=ORIENT_SPHERICAL, ref_state=None,
                  subtract_off=True, viscosity=0.0, dynamic_viscosity=False,
                  hyperdiffusion_timescale=None, sources=0, boundary_conditions=(),
-                 param_set=None, smagorinsky=None, discrete_hydrostatic_balance=False):
+                 param_set=None, smagorinsky=None, discrete_hydrostatic_balance=False,
+                 with_divergence=False, zero_enthalpy=False):
+        # ConstantViscosity(..., WithDivergence()) (TurbulenceClosures.jl:290-370) and the
+        # total_specific_enthalpy == 0 override of mms_bc_atmos.jl:50-51
+        self.with_divergence, self.zero_enthalpy = bool(with_divergence), bool(zero_enthalpy)
         # ref_state.jl:150-175: rho_ref = -k . grad(p_ref) / (k . grad Phi) with the DG gradient of
         # the reference pressure.  Needs the operator (device or oracle); off = analytic density
         self.discrete_hydrostatic_balance = bool(discrete_hydrostatic_balance)
@@ -280,6 +304,7 @@ class DryAtmosModel:
         for i, bc in enumerate(self.boundary_conditions):
             ip[7 + i] = bc
         ip[14] = 1 if self.C_smag is not None else 0
+        ip[15] = int(self.with_divergence) | (int(self.zero_enthalpy) << 1)
         dp = np.zeros(32)
         dp[0] = self.viscosity
         dp[1] = self.tau_hyper if self.tau_hyper is not None else 0.0

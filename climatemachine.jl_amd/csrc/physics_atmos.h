@@ -15,7 +15,10 @@
 // orientation, [1] hydrostatic reference state, [2] subtract_off, [3] viscosity kind,
 // [4] DryBiharmonic, [5] source bits, [6] nbc, [7..13] bc kinds; dparam[0] viscosity,
 // [1] tau, [2..12] R_d cp_d cv_d T_0 grav Omega MSLP day planet_radius inv_Pr_turb kappa_d,
-// [13] C_smag; iparam[14] turbulence closure (0 constant viscosity, 1 SmagorinskyLilly).
+// [13] C_smag; iparam[14] turbulence closure (0 constant viscosity, 1 SmagorinskyLilly);
+// iparam[15] bit 0 WithDivergence stress, bit 1 total_specific_enthalpy == 0 (the override of
+// test/Numerics/DGMethods/compressible_Navier_Stokes/mms_bc_atmos.jl:50-51).  Source bit 8 =
+// MMSSource{3}, boundary kind 2 = InitStateBC with the manufactured solution (same test).
 #pragma once
 #include "cmdg_common.h"
 
@@ -25,6 +28,7 @@ struct AtmosParams {
     int orient, subtract, kinematic, src, nbc;
     int bc[8];
     double visc, tau, R_d, cp_d, cv_d, T_0, grav, Omega, MSLP, day, invPr, C_smag;
+    int withdiv, zero_h;  // WithDivergence stress; total_specific_enthalpy overridden to zero
 };
 
 template <bool ORIENT, bool REF, bool HYPER, bool SMAG = false>
@@ -90,6 +94,8 @@ struct DryAtmos {
         p.day = dp[9];
         p.invPr = dp[11];
         p.C_smag = dp[13];
+        p.withdiv = ip[15] & 1;
+        p.zero_h = (ip[15] >> 1) & 1;
     }
 
     // ---- dry thermodynamics ----------------------------------------------------------
@@ -222,6 +228,13 @@ struct DryAtmos {
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int c = 0; c < 3; ++c) tau[d + 3 * c] = (-2 * nu[d]) * sym(S, d, c);
+        if constexpr (!SMAG) {
+            if (m.withdiv) {  // compute_stress(::WithDivergence, nu, S) (:369-370)
+                const double trS = S[0] + S[3] + S[5];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) tau[d + 3 * d] += (2 * nu[d] / 3) * trS;
+            }
+        }
     }
     __device__ static void flux_second_order(const Params &m, double *F, const double *Q,
                                              const double *gf, const double *hyp, const double *aux,
@@ -280,7 +293,7 @@ struct DryAtmos {
         k_v = k_f * hf;
     }
     __device__ static void source(const Params &m, double *S, const double *Q, const double *,
-                                  const double *aux, const double *der, double, int)
+                                  const double *aux, const double *der, double t, int)
     {
         const double rho = Q[0];
         double Sm[3] = {0, 0, 0}, Se = 0;
@@ -327,6 +340,100 @@ struct DryAtmos {
         S[2] = Sm[1];
         S[3] = Sm[2];
         S[4] = Se;
+        if constexpr (!ORIENT && !REF && !HYPER && !SMAG) {
+            if (m.src & 8) {  // MMSSource{3} (mms_bc_atmos.jl:65-86)
+                double Sx[5];
+                mms_source(m, t, aux[0], aux[1], aux[2], Sx);
+#pragma unroll
+                for (int q = 0; q < 5; ++q) S[q] = q == 0 || first ? Sx[q] : S[q] + Sx[q];
+            }
+        }
+    }
+    // ---- manufactured solution of mms_bc_atmos.jl (dim = 3; its generating script is
+    // mms_solution.jl:10-100): rho = c g + 3, u = v = c g, w = c h, E = c g + 100 with
+    // c = cos(pi t), g = sin(pi x) cos(pi y) cos(pi z), h = sin(pi x) cos(pi y) sin(pi z);
+    // P = (gamma - 1)(E - rho |u|^2 / 2), tau = 2 mu (eps - tr(eps) / 3), no heat conduction.
+    __device__ static void mms_state(double t, double x, double y, double z, double *Q)
+    {
+        const double pi = 3.14159265358979323846;
+        const double c = cos(pi * t), g = sin(pi * x) * cos(pi * y) * cos(pi * z);
+        const double h = sin(pi * x) * cos(pi * y) * sin(pi * z);
+        const double rho = g * c + 3;
+        Q[0] = rho;
+        Q[1] = rho * g * c;
+        Q[2] = rho * g * c;
+        Q[3] = rho * h * c;
+        Q[4] = g * c + 100;
+    }
+    // S = dq/dt + div F(q, grad q), evaluated from the analytic derivatives of g and h
+    __device__ static void mms_source(const Params &m, double t, double x, double y, double z,
+                                      double *S)
+    {
+        const double pi = 3.14159265358979323846, pi2 = pi * pi;
+        const double gam = m.cp_d / m.cv_d, mu = m.visc;
+        const double ct = cos(pi * t), st = sin(pi * t);
+        const double sx = sin(pi * x), cx = cos(pi * x), sy = sin(pi * y), cy = cos(pi * y);
+        const double sz = sin(pi * z), cz = cos(pi * z);
+        const double g = sx * cy * cz, h = sx * cy * sz;
+        const double dg[3] = {pi * cx * cy * cz, -pi * sx * sy * cz, -pi * sx * cy * sz};
+        const double dh[3] = {pi * cx * cy * sz, -pi * sx * sy * sz, pi * sx * cy * cz};
+        // second derivatives, symmetric storage [xx, xy, xz, yy, yz, zz]
+        const double Hg[6] = {-pi2 * g, -pi2 * cx * sy * cz, -pi2 * cx * cy * sz,
+                              -pi2 * g, pi2 * sx * sy * sz, -pi2 * g};
+        const double Hh[6] = {-pi2 * h, -pi2 * cx * sy * sz, pi2 * cx * cy * cz,
+                              -pi2 * h, -pi2 * sx * sy * cz, -pi2 * h};
+        auto H = [](const double *A, int i, int j) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            return A[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)];
+        };
+        const double rho = ct * g + 3, rho_t = -pi * st * g, E = ct * g + 100, E_t = -pi * st * g;
+        double u[3] = {ct * g, ct * g, ct * h}, u_t[3] = {-pi * st * g, -pi * st * g, -pi * st * h};
+        double drho[3], dE[3], du[3][3];  // du[i][j] = d u_i / d x_j
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            drho[j] = ct * dg[j];
+            dE[j] = ct * dg[j];
+            du[0][j] = ct * dg[j];
+            du[1][j] = ct * dg[j];
+            du[2][j] = ct * dh[j];
+        }
+        const double divu = du[0][0] + du[1][1] + du[2][2];
+        double lap[3], ddiv[3];  // laplacian of u_i; gradient of div u
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double *A = i == 2 ? Hh : Hg;
+            lap[i] = ct * (H(A, 0, 0) + H(A, 1, 1) + H(A, 2, 2));
+            ddiv[i] = ct * (H(Hg, i, 0) + H(Hg, i, 1) + H(Hh, i, 2));
+        }
+        const double ke = (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) / 2;
+        double dke[3], dP[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dke[j] = u[0] * du[0][j] + u[1] * du[1][j] + u[2] * du[2][j];
+        const double P = (gam - 1) * (E - rho * ke);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dP[j] = (gam - 1) * (dE[j] - drho[j] * ke - rho * dke[j]);
+        const double udrho = u[0] * drho[0] + u[1] * drho[1] + u[2] * drho[2];
+        const double divm = udrho + rho * divu;  // div(rho u)
+        S[0] = rho_t + divm;
+        double dtau[3];  // d_j tau_ij
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            dtau[i] = mu * (lap[i] + ddiv[i] / 3);
+            const double adv = u[0] * du[i][0] + u[1] * du[i][1] + u[2] * du[i][2];
+            S[1 + i] = rho_t * u[i] + rho * u_t[i] + u[i] * divm + rho * adv + dP[i] - dtau[i];
+        }
+        double work = 0;  // d_j (u_i tau_ij)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            work += u[i] * dtau[i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double tau = mu * (du[i][j] + du[j][i]) - (i == j ? 2 * mu / 3 * divu : 0.0);
+                work += du[i][j] * tau;
+            }
+        }
+        const double udEP = u[0] * (dE[0] + dP[0]) + u[1] * (dE[1] + dP[1]) + u[2] * (dE[2] + dP[2]);
+        S[4] = E_t + (E + P) * divu + udEP - work;
     }
     __device__ static void gradient_argument(const Params &m, double *G, const double *Q,
                                              const double *aux, double)
@@ -336,7 +443,7 @@ struct DryAtmos {
         for (int d = 0; d < 3; ++d) G[d] = rhoinv * Q[1 + d];
         const double T = air_T(m, internal_energy(m, Q, aux));
         const double e_tot = Q[4] * (1 / Q[0]);
-        G[3] = e_tot + m.R_d * T;
+        G[3] = m.zero_h ? 0.0 : e_tot + m.R_d * T;
         // transform.turbulence.theta_v = aux.moisture.theta_v (:441-449).  The aux entry is
         // the nodal refresh of this same (Q, aux) -- evaluated here so that the fused refresh
         // of neighbouring elements is never read (see FUSE_UPDATE_AUX)
@@ -413,6 +520,10 @@ struct DryAtmos {
                                           double *auxP, const double *n, const double *QM,
                                           const double *, double t, const double *, const double *)
     {
+        if (m.bc[bctag - 1] == 2) {  // InitStateBC (bc_initstate.jl:12-26): the exact solution
+            mms_state(t, auxP[0], auxP[1], auxP[2], QP);
+            return;
+        }
         if (m.bc[bctag - 1] == 1) {  // Impenetrable(FreeSlip) + Insulating
             const double dn = QM[1] * n[0] + QM[2] * n[1] + QM[3] * n[2];
             const double f = kind == BS_FIRST ? 2 * dn : dn;
@@ -421,14 +532,26 @@ struct DryAtmos {
         }
         update_aux(m, QP, auxP, t);
     }
-    // normal_boundary_flux_second_order! of AtmosBC: FreeSlip and Insulating add nothing
-    __device__ static void boundary_flux_second_order(const Params &, int, double *, double *,
-                                                      double *, double *, double *, const double *,
+    // normal_boundary_flux_second_order! of AtmosBC: FreeSlip and Insulating add nothing.
+    // InitStateBC takes the generic boundary_flux_second_order! (NumericalFluxes.jl:925-967):
+    // boundary_state! puts the exact solution on the plus side (bc_initstate.jl:28-46), the
+    // gradient flux there is the copy of the minus side, then flux_second_order! of that side.
+    __device__ static void boundary_flux_second_order(const Params &m, int bctag, double *F,
+                                                      double *QP, double *gfP, double *hypP,
+                                                      double *auxP, const double *,
                                                       const double *, const double *,
-                                                      const double *, const double *, double,
                                                       const double *, const double *,
+                                                      double t, const double *, const double *,
                                                       const double *)
     {
+        if (m.bc[bctag - 1] != 2) return;
+        mms_state(t, auxP[0], auxP[1], auxP[2], QP);
+        double FPl[15];
+#pragma unroll
+        for (int q = 0; q < 15; ++q) FPl[q] = -0.0;
+        flux_second_order(m, FPl, QP, gfP, hypP, auxP, t);
+#pragma unroll
+        for (int q = 0; q < 15; ++q) F[q] += FPl[q];
     }
     __device__ static void boundary_state_divergence(const Params &, int, double *, double *,
                                                      const double *, const double *,

@@ -29,7 +29,7 @@
 #include "dg_oracle.h"
 
 typedef struct {
-    int orient, ref, subtract, kinematic, hyper, src, nbc, bc[8], smag;
+    int orient, ref, subtract, kinematic, hyper, src, nbc, bc[8], smag, withdiv, zero_h;
     double visc, tau, R_d, cp_d, cv_d, T_0, grav, Omega, MSLP, day, a, invPr, kappa, C_smag;
     int oPhi, oRef, oTurb, oDelta, oMoist;
 } atmos_t;
@@ -109,6 +109,10 @@ static void turbulence_tensors(const atmos_t *m, const double *Q, const double *
     }
     for (int d = 0; d < 3; ++d)
         for (int c = 0; c < 3; ++c) tau[d + 3 * c] = (-2 * nu[d]) * sym(S, d, c);
+    if (!m->smag && m->withdiv) { /* (-2 nu) S + (2 nu / 3) tr(S) I */
+        const double trS = S[0] + S[3] + S[5];
+        for (int d = 0; d < 3; ++d) tau[d + 3 * d] += (2 * nu[d] / 3) * trS;
+    }
 }
 
 static void at_flux2(const void *p_, double *F, const double *Q, const double *gf, const double *hyp,
@@ -163,11 +167,84 @@ static void hs_coeffs(const atmos_t *m, const double *Q, const double *aux, doub
     *k_v = k_f * hf;
 }
 
+/* ---- manufactured solution of test/Numerics/DGMethods/compressible_Navier_Stokes/
+   mms_bc_atmos.jl, dim = 3 (generated by mms_solution.jl:10-100):
+     rho = c g + 3,  u = v = c g,  w = c h,  E = c g + 100,
+     c = cos(pi t), g = sin(pi x) cos(pi y) cos(pi z), h = sin(pi x) cos(pi y) sin(pi z),
+     P = (gamma - 1)(E - rho |u|^2 / 2), tau = 2 mu (eps - tr(eps)/3 I), no heat conduction.
+   The source S = dq/dt + div F is assembled from the analytic derivatives of g and h. */
+static void mms_state(double t, const double *x, double *Q)
+{
+    const double c = cos(M_PI * t);
+    const double g = sin(M_PI * x[0]) * cos(M_PI * x[1]) * cos(M_PI * x[2]);
+    const double h = sin(M_PI * x[0]) * cos(M_PI * x[1]) * sin(M_PI * x[2]);
+    const double rho = g * c + 3;
+    Q[0] = rho;
+    Q[1] = rho * g * c;
+    Q[2] = rho * g * c;
+    Q[3] = rho * h * c;
+    Q[4] = g * c + 100;
+}
+static void mms_source(const atmos_t *m, double t, const double *x, double *S)
+{
+    const double gam = m->cp_d / m->cv_d, mu = m->visc, P2 = M_PI * M_PI;
+    const double ct = cos(M_PI * t), st = sin(M_PI * t);
+    const double sx = sin(M_PI * x[0]), cx = cos(M_PI * x[0]);
+    const double sy = sin(M_PI * x[1]), cy = cos(M_PI * x[1]);
+    const double sz = sin(M_PI * x[2]), cz = cos(M_PI * x[2]);
+    const double g = sx * cy * cz, h = sx * cy * sz;
+    /* f[0] = g (for u, v, rho, E), f[1] = h (for w): value, gradient, Hessian */
+    const double df[2][3] = {{M_PI * cx * cy * cz, -M_PI * sx * sy * cz, -M_PI * sx * cy * sz},
+                             {M_PI * cx * cy * sz, -M_PI * sx * sy * sz, M_PI * sx * cy * cz}};
+    const double Hf[2][3][3] = {
+        {{-P2 * g, -P2 * cx * sy * cz, -P2 * cx * cy * sz},
+         {-P2 * cx * sy * cz, -P2 * g, P2 * sx * sy * sz},
+         {-P2 * cx * cy * sz, P2 * sx * sy * sz, -P2 * g}},
+        {{-P2 * h, -P2 * cx * sy * sz, P2 * cx * cy * cz},
+         {-P2 * cx * sy * sz, -P2 * h, -P2 * sx * sy * cz},
+         {P2 * cx * cy * cz, -P2 * sx * sy * cz, -P2 * h}}};
+    const int which[3] = {0, 0, 1};
+    const double fv[2] = {g, h};
+    const double rho = ct * g + 3, rho_t = -M_PI * st * g, E = ct * g + 100, E_t = -M_PI * st * g;
+    double u[3], u_t[3], du[3][3], lap[3], ddiv[3], drho[3], dE[3];
+    for (int i = 0; i < 3; ++i) {
+        u[i] = ct * fv[which[i]];
+        u_t[i] = -M_PI * st * fv[which[i]];
+        for (int j = 0; j < 3; ++j) du[i][j] = ct * df[which[i]][j];
+        lap[i] = ct * (Hf[which[i]][0][0] + Hf[which[i]][1][1] + Hf[which[i]][2][2]);
+        drho[i] = ct * df[0][i];
+        dE[i] = ct * df[0][i];
+    }
+    for (int j = 0; j < 3; ++j) { /* d_j (d_i u_i) */
+        ddiv[j] = 0;
+        for (int i = 0; i < 3; ++i) ddiv[j] += ct * Hf[which[i]][i][j];
+    }
+    const double divu = du[0][0] + du[1][1] + du[2][2];
+    const double ke = (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) / 2;
+    double dke[3], dP[3];
+    for (int j = 0; j < 3; ++j) dke[j] = u[0] * du[0][j] + u[1] * du[1][j] + u[2] * du[2][j];
+    const double P = (gam - 1) * (E - rho * ke);
+    for (int j = 0; j < 3; ++j) dP[j] = (gam - 1) * (dE[j] - drho[j] * ke - rho * dke[j]);
+    const double divm = (u[0] * drho[0] + u[1] * drho[1] + u[2] * drho[2]) + rho * divu;
+    S[0] = rho_t + divm;
+    double dtau[3], work = 0;
+    for (int i = 0; i < 3; ++i) {
+        dtau[i] = mu * (lap[i] + ddiv[i] / 3);
+        const double adv = u[0] * du[i][0] + u[1] * du[i][1] + u[2] * du[i][2];
+        S[1 + i] = rho_t * u[i] + rho * u_t[i] + u[i] * divm + rho * adv + dP[i] - dtau[i];
+        work += u[i] * dtau[i];
+        for (int j = 0; j < 3; ++j)
+            work += du[i][j] * (mu * (du[i][j] + du[j][i]) - (i == j ? 2 * mu / 3 * divu : 0.0));
+    }
+    S[4] = E_t + (E + P) * divu +
+           (u[0] * (dE[0] + dP[0]) + u[1] * (dE[1] + dP[1]) + u[2] * (dE[2] + dP[2])) - work;
+}
+
 static void at_source(const void *p_, double *S, const double *Q, const double *gf, const double *aux,
                       double t, int dir)
 {
     const atmos_t *m = (const atmos_t *)p_;
-    (void)gf; (void)t; (void)dir;
+    (void)gf; (void)dir;
     const double rho = Q[0];
     double Sm[3] = {0, 0, 0}, Se = 0;
     int first = 1, firste = 1;
@@ -208,6 +285,13 @@ static void at_source(const void *p_, double *S, const double *Q, const double *
     S[2] = Sm[1];
     S[3] = Sm[2];
     S[4] = Se;
+    if (m->src & 8) { /* MMSSource{3} (mms_bc_atmos.jl:65-86) */
+        double Sx[5];
+        mms_source(m, t, aux, Sx);
+        S[0] = Sx[0];
+        for (int q = 1; q < 4; ++q) S[q] = first ? Sx[q] : S[q] + Sx[q];
+        S[4] = firste ? Sx[4] : S[4] + Sx[4];
+    }
 }
 
 static void at_gradarg(const void *p_, double *G, const double *Q, const double *aux, double t)
@@ -218,7 +302,7 @@ static void at_gradarg(const void *p_, double *G, const double *Q, const double 
     for (int d = 0; d < 3; ++d) G[d] = rhoinv * Q[1 + d];
     const double T = air_T(m, internal_energy(m, Q, aux));
     const double e_tot = Q[4] * (1 / Q[0]);
-    G[3] = e_tot + m->R_d * T;
+    G[3] = m->zero_h ? 0.0 : e_tot + m->R_d * T;
     if (m->smag) G[4] = aux[m->oMoist]; /* transform.turbulence.theta_v = aux.moisture.theta_v */
     if (m->hyper) {
         double u[3], k[3];
@@ -292,7 +376,11 @@ static void at_bstate(const void *p_, int kind, int bctag, double *QP, double *a
                       const double *aux1)
 {
     const atmos_t *m = (const atmos_t *)p_;
-    (void)auxM; (void)t; (void)Q1; (void)aux1;
+    (void)auxM; (void)Q1; (void)aux1;
+    if (m->bc[bctag - 1] == 2) { /* InitStateBC (bc_initstate.jl:12-26) */
+        mms_state(t, auxP, QP);
+        return;
+    }
     if (m->bc[bctag - 1] == 1) {
         const double dn = QM[1] * n[0] + QM[2] * n[1] + QM[3] * n[2];
         const double f = kind == ORC_BS_FIRST ? 2 * dn : dn;
@@ -307,8 +395,18 @@ static void at_bflux2(const void *p_, int bctag, double *F, double *QP, double *
                       const double *hypM, const double *auxM, double t, const double *Q1,
                       const double *gf1, const double *aux1)
 {
-    (void)p_; (void)bctag; (void)F; (void)QP; (void)gfP; (void)hypP; (void)auxP; (void)n; (void)QM;
-    (void)gfM; (void)hypM; (void)auxM; (void)t; (void)Q1; (void)gf1; (void)aux1;
+    const atmos_t *m = (const atmos_t *)p_;
+    (void)n; (void)Q1; (void)gf1; (void)aux1;
+    if (m->bc[bctag - 1] != 2) return;
+    /* InitStateBC: generic boundary_flux_second_order! (NumericalFluxes.jl:925-967) --
+       boundary_state! puts the exact solution on the plus side (bc_initstate.jl:28-46), the
+       gradient flux there is the copy of the minus side, then flux_second_order! of the plus side */
+    (void)QM; (void)gfM; (void)hypM; (void)auxM;
+    mms_state(t, auxP, QP);
+    double FP[15];
+    for (int q = 0; q < 15; ++q) FP[q] = -0.0;
+    at_flux2(p_, FP, QP, gfP, hypP, auxP, t);
+    for (int q = 0; q < 15; ++q) F[q] += FP[q];
 }
 static void at_bdiv(const void *p_, int bctag, double *gradP, double *auxP, const double *n,
                     const double *gradM, const double *auxM, double t)
@@ -384,6 +482,8 @@ orc_physics *orc_atmos_new(const int *ip, const double *dp, int nf_first)
     m->kappa = dp[12];
     m->C_smag = dp[13];
     m->smag = ip[14] == 1;
+    m->withdiv = ip[15] & 1;        /* WithDivergence (TurbulenceClosures.jl:369-370) */
+    m->zero_h = (ip[15] >> 1) & 1;  /* total_specific_enthalpy == 0 (mms_bc_atmos.jl:50-51) */
     int o = 3;
     m->oPhi = o;   o += m->orient ? 4 : 0;
     m->oRef = o;   o += m->ref ? 7 : 0;

@@ -319,3 +319,32 @@ def check_split_explicit_table(table, parr, fields, slack=2.0):
             worst = max(worst, rel * 10.0 ** p)
             assert rel <= slack * 10.0 ** (-p), (key, j, got[j], ref, rel)
     return worst
+
+
+def mms_atmos_setup(level=1, N=4):
+    """test/Numerics/DGMethods/compressible_Navier_Stokes/mms_bc_atmos.jl, dim = 3: unit cube,
+    (4 * 2^(level-1))^3 elements, warped (:252-262), every face InitStateBC; dry AtmosModel with
+    ConstantDynamicViscosity(1/100, WithDivergence()), NoReferenceState, NoOrientation,
+    T_0 = 0, total_specific_enthalpy == 0, MMSSource{3}; dt = 5e-3 / Ne rounded to divide 1.
+    (The reference builds a BrickTopology; the stacked topology holds the same elements in another
+    order, which the error norm does not see.)"""
+    A = cm.atmos
+    ps = A.PlanetParameters()
+    ps.T_0 = 0.0
+    Ne = 4 * 2 ** (level - 1)
+    r = np.linspace(0.0, 1.0, Ne + 1)
+    topl = M.StackedBrickTopology([r, r, r], periodicity=(False, False, False),
+                                  boundary=((1, 1), (1, 1), (1, 1)))
+
+    def warp(x1, x2, x3):
+        return (x1 + (x1 - 1 / 2) * np.cos(2 * np.pi * x2 * x3) / 4,
+                x2 + np.exp(np.sin(2 * np.pi * (x1 * x2 + x3))) / 20,
+                x3 + x1 / 4 + x2 ** 2 / 2 + np.sin(x1 * x2 * x3))
+
+    grid = M.DiscontinuousSpectralElementGrid(topl, N, meshwarp=warp)
+    law = A.DryAtmosModel(A.MMSSetup(ps), orientation=A.ORIENT_NONE, ref_state=None,
+                          viscosity=1 / 100, dynamic_viscosity=True, with_divergence=True,
+                          zero_enthalpy=True, sources=A.SRC_MMS,
+                          boundary_conditions=(A.BC_INIT_STATE_MMS,), param_set=ps)
+    nsteps = int(np.ceil(1.0 / (5e-3 / Ne)))
+    return law, grid, 1.0 / nsteps, nsteps
