@@ -131,7 +131,7 @@ def test_local_multirank_matches_single_rank(cm, oracle, torch, size):
 
 def test_fails_loudly_without_fallback(cm):
     """No CPU fallback: a physics / order that is not compiled in is an error."""
-    law, grid, _ = pseudo1d_setup(Ne=2, N=3)
+    law, grid, _ = pseudo1d_setup(Ne=2, N=8)         # compiled in: N = 1..7
     with pytest.raises(cm._lib.CmdgError):
         cm.dgmodel.DGModel(law, grid)
 
