@@ -332,14 +332,7 @@ class DryAtmosModel:
             aux[:, self.off_phi, :] = phi
             # auxiliary_field_gradient!: element-local strong gradient
             # (dgsem_auxiliary_field_gradient!, DGModel_kernels.jl:3097-3232)
-            Nq = list(grid.Nq)
-            dphi = [G._apply_D(grid.D[b], phi, b, Nq) for b in range(3)]
-            mets = [(G._xi1x1, G._xi1x2, G._xi1x3), (G._xi2x1, G._xi2x2, G._xi2x3),
-                    (G._xi3x1, G._xi3x2, G._xi3x3)]
-            for d in range(3):
-                g = (vg[:, mets[0][d], :] * dphi[0] + vg[:, mets[1][d], :] * dphi[1]) \
-                    + vg[:, mets[2][d], :] * dphi[2]
-                aux[:, self.off_phi + 1 + d, :] = g
+            aux[:, self.off_phi + 1:self.off_phi + 4, :] = G.auxiliary_field_gradient(grid, phi)
         if self.ref_state is not None:
             # ref_state_init_p_rho! and ref_state_finalize_init! (ref_state.jl:70-140).  The
             # reference additionally re-derives rho from a DG gradient of p (discrete

@@ -380,3 +380,22 @@ def min_node_distance(grid, direction=0):
         diff = np.diff(x, axis=npax)
         md = min(md, float(np.sqrt((diff ** 2).sum(axis=-1)).min()))
     return md
+
+
+def auxiliary_field_gradient(grid, a, direction=0):
+    """``auxiliary_field_gradient!`` (kernel ``dgsem_auxiliary_field_gradient!``,
+    DGModel_kernels.jl:3097-3232): the element-local strong-form gradient of a nodal field
+    ``a`` (nelem, Np), no face terms.  ``direction`` 0 = Every (the horizontal launch, then the
+    vertical one incrementing), 1 = Horizontal (xi_1, xi_2 terms), 2 = Vertical (xi_3 term).
+    Returns (nelem, 3, Np).  One-time host work (orientation gradient, reference-state setup)."""
+    vg, Nq = grid.vgeo, list(grid.Nq)
+    out = np.zeros((a.shape[0], 3, a.shape[1]))
+    if direction in (0, 1):
+        d1, d2 = _apply_D(grid.D[0], a, 0, Nq), _apply_D(grid.D[1], a, 1, Nq)
+        for d, (c1, c2) in enumerate(((_xi1x1, _xi2x1), (_xi1x2, _xi2x2), (_xi1x3, _xi2x3))):
+            out[:, d, :] = vg[:, c1, :] * d1 + vg[:, c2, :] * d2
+    if direction in (0, 2):
+        d3 = _apply_D(grid.D[2], a, 2, Nq)
+        for d, c3 in enumerate((_xi3x1, _xi3x2, _xi3x3)):
+            out[:, d, :] = out[:, d, :] + vg[:, c3, :] * d3
+    return out
