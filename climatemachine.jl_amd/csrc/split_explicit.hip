@@ -105,6 +105,16 @@ int lsrk_update(EngineBase *e, double *dQ, double *Q, double rka_next, double rk
     return CMDG_OK;
 }
 
+// update! of StrongStabilityPreservingRungeKuttaMethod.jl:167-190
+__global__ void k_ssprk_update(const double *__restrict__ R, const double *__restrict__ Q,
+                               double *__restrict__ Qstage, double rka1, double rka2, double rkb,
+                               double dt, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        Qstage[i] = rka1 * Q[i] + rka2 * Qstage[i] + dt * rkb * R[i];
+}
+
 int launch_status(EngineBase *e)
 {
     hipError_t r = hipGetLastError();
@@ -147,6 +157,31 @@ int cmdg_lsrk_update(cmdg_handle h, double *dQ, double *Q, double rka_next, doub
     if (!h || !dQ || !Q) return CMDG_ERR_INVALID;
     lsrk_update(h->eng, dQ, Q, rka_next, rkb_dt);
     return set_err2(h, launch_status(h->eng));
+}
+
+int cmdg_ssprk_step(cmdg_handle h, double *Q, double *Rstage, double *Qstage, double t, double dt,
+                    int32_t nstages, const double *rka, const double *rkb, const double *rkc)
+{
+    if (!h || !Q || !Rstage || !Qstage || !rka || !rkb || !rkc || nstages < 1) return CMDG_ERR_INVALID;
+    EngineBase *e = h->eng;
+    const int64_t n = (int64_t)e->Np * e->ns * e->nreal;
+    if (hipMemcpyAsync(Qstage, Q, sizeof(double) * n, hipMemcpyDeviceToDevice, e->s_comp) != hipSuccess)
+        return set_err2(h, e->fail(CMDG_ERR_HIP, "ssprk: copy failed"));
+    for (int s = 0; s < nstages; ++s) {
+        RhsCtx c;
+        c.tendency = Rstage;
+        c.Qin = Qstage;
+        c.t = t + rkc[s] * dt;
+        c.alpha = 1.0;
+        c.beta = 0.0;
+        if (int r = e->rhs_async(c)) return set_err2(h, r);
+        hipLaunchKernelGGL(k_ssprk_update, dim3(nblocks(n)), dim3(256), 0, e->s_comp,
+                           (const double *)Rstage, (const double *)Q, Qstage, rka[2 * s],
+                           rka[2 * s + 1], rkb[s], dt, n);
+    }
+    if (hipMemcpyAsync(Q, Qstage, sizeof(double) * n, hipMemcpyDeviceToDevice, e->s_comp) != hipSuccess)
+        return set_err2(h, e->fail(CMDG_ERR_HIP, "ssprk: copy failed"));
+    return set_err2(h, launch_status(e));
 }
 
 int cmdg_split_explicit_step(cmdg_handle slow, cmdg_handle fast, const cmdg_ocean_coupling_desc *d,

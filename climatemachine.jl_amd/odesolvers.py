@@ -4,7 +4,9 @@ Reference: ``LowStorageRungeKutta2N`` / ``dostep!`` / ``update!``
 ``src/Numerics/ODESolvers/LowStorageRungeKuttaMethod.jl:26-62,102-158``;
 ``LSRK54CarpenterKennedy`` ``:293-327`` (rational coefficients converted to Float64),
 ``LSRK144NiegemannDiehlBusch`` ``:349-410``;
-``solve!`` / ``general_dostep!`` ``ODESolvers.jl:49-158``.
+``solve!`` / ``general_dostep!`` ``ODESolvers.jl:49-158``;
+``StrongStabilityPreservingRungeKutta`` and its four tableaus
+``StrongStabilityPreservingRungeKuttaMethod.jl:27-285``.
 
 The stage loop itself runs inside libcmdg (``cmdg_lsrk_run``): five fused
 RHS+update passes per step, enqueued without host synchronisation.
@@ -12,7 +14,9 @@ RHS+update passes per step, enqueued without host synchronisation.
 from fractions import Fraction
 
 __all__ = ["LSRK54CarpenterKennedy", "LSRK144NiegemannDiehlBusch", "solve",
-           "LowStorageRungeKutta2N", "LSRK144_COEFFICIENTS"]
+           "LowStorageRungeKutta2N", "LSRK144_COEFFICIENTS", "StrongStabilityPreservingRungeKutta",
+           "SSPRK22Heuns", "SSPRK22Ralstons", "SSPRK33ShuOsher", "SSPRK34SpiteriRuuth",
+           "SSPRK_COEFFICIENTS"]
 
 
 def _f(num, den):
@@ -64,6 +68,55 @@ LSRK144_COEFFICIENTS = (
 def LSRK144NiegemannDiehlBusch(dg, Q, dt=0.0, t0=0.0):
     RKA, RKB, RKC = LSRK144_COEFFICIENTS
     return LowStorageRungeKutta2N(dg, RKA, RKB, RKC, Q, dt=dt, t0=t0)
+
+
+# (RKA rows, RKB, RKC) of StrongStabilityPreservingRungeKuttaMethod.jl:203-285: Heun, Ralston,
+# Shu & Osher (1988) three-stage third-order, Spiteri & Ruuth (2002) four-stage third-order
+SSPRK_COEFFICIENTS = {
+    "SSPRK22Heuns": (((1.0, 0.0), (1 / 2, 1 / 2)), (1.0, 1 / 2), (0.0, 1.0)),
+    "SSPRK22Ralstons": (((1.0, 0.0), (5 / 8, 3 / 8)), (_f(2, 3), 3 / 4), (0.0, _f(2, 3))),
+    "SSPRK33ShuOsher": (((1.0, 0.0), (3 / 4, 1 / 4), (_f(1, 3), _f(2, 3))),
+                        (1.0, 1 / 4, _f(2, 3)), (0.0, 1.0, 1 / 2)),
+    "SSPRK34SpiteriRuuth": (((1.0, 0.0), (0.0, 1.0), (_f(2, 3), _f(1, 3)), (0.0, 1.0)),
+                            (1 / 2, 1 / 2, _f(1, 6), 1 / 2), (0.0, 1 / 2, 1.0, 1 / 2)),
+}
+
+
+class StrongStabilityPreservingRungeKutta:
+    """``StrongStabilityPreservingRungeKutta(f, RKA, RKB, RKC, Q; dt, t0)``
+    (StrongStabilityPreservingRungeKuttaMethod.jl:27-75); the stage loop is ``cmdg_ssprk_step``."""
+
+    def __init__(self, dg, RKA, RKB, RKC, Q, dt=0.0, t0=0.0):
+        import numpy as np
+        self.dg, self.dt, self.t, self.steps = dg, dt, t0, 0
+        self.RKA = np.ascontiguousarray(RKA, dtype=np.float64)
+        self.RKB = np.ascontiguousarray(RKB, dtype=np.float64)
+        self.RKC = np.ascontiguousarray(RKC, dtype=np.float64)
+        self.Rstage = dg.create_state(Q.shape[1])
+        self.Qstage = dg.create_state(Q.shape[1])
+
+    def dostep(self, Q, nsteps=1, dt=None):
+        import ctypes as C
+        from . import _lib
+        dt = self.dt if dt is None else dt
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        self.dg._torch_ready()
+        for i in range(int(nsteps)):
+            _lib.check(self.dg.L.cmdg_ssprk_step(
+                self.dg.handle, Q.data_ptr(), self.Rstage.data_ptr(), self.Qstage.data_ptr(),
+                float(self.t + i * dt), float(dt), len(self.RKB), p(self.RKA), p(self.RKB),
+                p(self.RKC)), self.dg.handle)
+
+
+def _ssp(name):
+    def make(dg, Q, dt=0.0, t0=0.0):
+        return StrongStabilityPreservingRungeKutta(dg, *SSPRK_COEFFICIENTS[name], Q, dt=dt, t0=t0)
+    make.__name__ = name
+    return make
+
+
+SSPRK22Heuns, SSPRK22Ralstons = _ssp("SSPRK22Heuns"), _ssp("SSPRK22Ralstons")
+SSPRK33ShuOsher, SSPRK34SpiteriRuuth = _ssp("SSPRK33ShuOsher"), _ssp("SSPRK34SpiteriRuuth")
 
 
 def solve(Q, solver, timeend=None, numberofsteps=0, adjustfinalstep=True):

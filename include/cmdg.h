@@ -313,6 +313,15 @@ int cmdg_ocean_reconcile_from_fast_to_slow(cmdg_handle slow, cmdg_handle fast,
 /* update!() of the LSRK methods on the handle's real elements (LowStorageRungeKuttaMethod.jl:
  * 146-166): Q += rkb_dt * dQ; dQ *= rka_next */
 int cmdg_lsrk_update(cmdg_handle h, double *dQ, double *Q, double rka_next, double rkb_dt);
+/* dostep!(Q, ssp::StrongStabilityPreservingRungeKutta, p, time)
+ * (src/Numerics/ODESolvers/StrongStabilityPreservingRungeKuttaMethod.jl:117-165, update! kernel
+ * :167-190): Qstage = Q; per stage Rstage = rhs(Qstage, t + rkc[s] dt) (increment = false) and
+ * Qstage = rka[2 s] Q + rka[2 s + 1] Qstage + dt rkb[s] Rstage; finally Q = Qstage.  rka is the
+ * (nstages, 2) coefficient matrix row-major; Rstage and Qstage are caller-owned arrays of Q's
+ * shape. */
+int cmdg_ssprk_step(cmdg_handle h, double *Q, double *Rstage, double *Qstage, double t, double dt,
+                    int32_t nstages, const double *rka, const double *rkb, const double *rkc);
+
 /* dostep!(Qslow, split::SplitExplicitSolver, param, time) (SplitExplicitMethod.jl:70-177): one
  * slow step of size dt_slow whose every stage sub-steps the fast model with full LSRK steps
  * of at most dt_fast.  dQ_slow / dQ_fast are the LSRK tendency accumulators (zero before the

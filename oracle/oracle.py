@@ -400,6 +400,17 @@ def lsrk_step(dg, Q, dQ, t, dt, rka, rkb, rkc, step_filter=None):
         apply_filter(Q, tg, dg.grid, f, direction=d, state_auxiliary=dg.state_auxiliary)
 
 
+def ssprk_step(dg, Q, Rstage, Qstage, t, dt, rka, rkb, rkc):
+    """``dostep!`` of StrongStabilityPreservingRungeKuttaMethod.jl:117-165 with the ``update!``
+    kernel of :167-190 on the real elements."""
+    nr = dg.grid.nreal
+    Qstage[:nr] = Q[:nr]
+    for s in range(len(rkb)):
+        dg(Rstage, Qstage, t + rkc[s] * dt, 1.0, 0.0)     # rhs!(...; increment = false)
+        Qstage[:nr] = rka[s][0] * Q[:nr] + rka[s][1] * Qstage[:nr] + dt * rkb[s] * Rstage[:nr]
+    Q[:nr] = Qstage[:nr]
+
+
 def solve(dg, Q, dt, timeend, t0=0.0):
     """``solve!`` with ``adjustfinalstep = true`` (ODESolvers.jl:49-158)."""
     dQ = np.zeros_like(Q)

@@ -177,7 +177,7 @@ def ocean_windstress_setup(Nx=5, Ny=5, Nz=5, N=4, rank=0, size=1):
     return law, grid
 
 
-def advection_sphere_setup(level=1, N=4, rank=0, size=1, problem="SolidBodyRotation"):
+def advection_sphere_setup(level=1, N=4, rank=0, size=1, problem="SolidBodyRotation", cfl=5.0):
     """test/Numerics/DGMethods/advection_diffusion/advection_sphere.jl:303-430
     (SolidBodyRotation, LSRK144 at CFL 5): cubed sphere of 2^(level-1) * 2 elements per edge,
     one element between R = 1 and R = 2, NoFlowBC on both shells, advection only, Rusanov."""
@@ -187,7 +187,7 @@ def advection_sphere_setup(level=1, N=4, rank=0, size=1, problem="SolidBodyRotat
     prob = getattr(BL, problem)()
     law = BL.AdvectionDiffusion(3, prob, (BL.NoFlowBC(),), diffusion=False)
     dx = M.grids.min_node_distance(grid, 1)
-    dt = 5.0 * dx / prob.u_scale
+    dt = cfl * dx / prob.u_scale
     dt = prob.finaltime / np.ceil(prob.finaltime / dt)
     return law, grid, dt
 

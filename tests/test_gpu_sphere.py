@@ -1,4 +1,5 @@
-"""Cubed-sphere golden values on the GPU: advection_sphere.jl levels 1-4 and
+"""Cubed-sphere golden values on the GPU: advection_sphere.jl levels 1-4 (LSRK144 and the two
+SSPRK steppers) and
 diffusion_hyperdiffusion_sphere.jl levels 1-3 (N = 3) through libcmdg.  ``-m gpu``."""
 import json
 import os
@@ -31,6 +32,25 @@ def test_sphere_advection_on_the_gpu(cm, torch, problem, level):
     err = dg.euclidean_distance(Q, Qe)
     g = GOLD["advection_sphere"]
     exp = g[problem + "_LSRK144"][level - 1]
+    assert abs(err - exp) <= g["rtol"] * exp, (err, exp)
+    assert abs(err - exp) <= 1e-9 * exp
+    dg.close()
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+@pytest.mark.parametrize("method", ["SSPRK33", "SSPRK34"])
+@pytest.mark.parametrize("problem", ["SolidBodyRotation", "ReversingDeformationalFlow"])
+def test_sphere_advection_ssprk_on_the_gpu(cm, torch, problem, method, level):
+    g = GOLD["advection_sphere"]
+    law, grid, dt = advection_sphere_setup(level, problem=problem, cfl=g["max_cfl"][method])
+    dg = cm.dgmodel.DGModel(law, grid)
+    Q = dg.init_ode_state(0.0)
+    Qe = Q.clone()
+    make = {"SSPRK33": cm.odesolvers.SSPRK33ShuOsher, "SSPRK34": cm.odesolvers.SSPRK34SpiteriRuuth}
+    solver = make[method](dg, Q, dt=dt)
+    cm.odesolvers.solve(Q, solver, timeend=law.problem.finaltime)
+    err = dg.euclidean_distance(Q, Qe)
+    exp = g["%s_%s" % (problem, method)][level - 1]
     assert abs(err - exp) <= g["rtol"] * exp, (err, exp)
     assert abs(err - exp) <= 1e-9 * exp
     dg.close()

@@ -41,6 +41,28 @@ def test_lsrk_order_oracle(oracle, method):
     assert abs(rate - 4) <= ATOL, (errors, rate)
 
 
+@pytest.mark.parametrize("method,order", [("SSPRK22Heuns", 2), ("SSPRK22Ralstons", 2),
+                                          ("SSPRK33ShuOsher", 3), ("SSPRK34SpiteriRuuth", 3)])
+def test_ssprk_order_oracle(oracle, method, order):
+    rka, rkb, rkc = cm.odesolvers.SSPRK_COEFFICIENTS[method]
+
+    class Rhs:
+        grid = types.SimpleNamespace(nreal=1)
+
+        def __call__(self, dQ, Q, t, alpha, beta):
+            dQ[...] = alpha * (Q * np.cos(t)) + beta * dQ
+
+    errors = []
+    for dt in DTS:
+        Q = Q0.reshape(1, 1, -1).copy()
+        R, Qs = np.zeros_like(Q), np.zeros_like(Q)
+        for i in range(int(round(FINAL / dt))):
+            oracle.ssprk_step(Rhs(), Q, R, Qs, i * dt, dt, rka, rkb, rkc)
+        errors.append(np.abs(Q.reshape(-1) - Q0 * np.exp(np.sin(FINAL))).max())
+    rate = np.log2(errors[0] / errors[1])
+    assert abs(rate - order) <= ATOL, (errors, rate)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("method", ["LSRK54CarpenterKennedy", "LSRK144NiegemannDiehlBusch"])
 def test_lsrk_order_device_update_kernel(oracle, method):

@@ -41,6 +41,31 @@ def test_sphere_advection_matches_reference_error(oracle, problem, level):
     assert abs(m1 - m0) / m0 <= 5e-14             # advection_sphere.jl:431
 
 
+@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("method", ["SSPRK33", "SSPRK34"])
+@pytest.mark.parametrize("problem", ["SolidBodyRotation", "ReversingDeformationalFlow"])
+def test_sphere_advection_ssprk_matches_reference_error(oracle, problem, method, level):
+    """The strong-stability-preserving steppers (advection_sphere.jl:313-317, 330-372)."""
+    g = GOLD["advection_sphere"]
+    law, grid, dt = advection_sphere_setup(level, problem=problem, cfl=g["max_cfl"][method])
+    rka, rkb, rkc = cm.odesolvers.SSPRK_COEFFICIENTS[
+        {"SSPRK33": "SSPRK33ShuOsher", "SSPRK34": "SSPRK34SpiteriRuuth"}[method]]
+    tend = law.problem.finaltime
+    dg = oracle.OracleDGModel(law, grid, nf_first=0)
+    Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
+    Qe = Q.copy()
+    R, Qs = np.zeros_like(Q), np.zeros_like(Q)
+    t = 0.0
+    while t < tend:
+        step = tend - t if t + dt > tend else dt
+        oracle.ssprk_step(dg, Q, R, Qs, t, step, rka, rkb, rkc)
+        t += step
+    err = np.sqrt(oracle.weighted_norm2_local(grid, Q, Qe))
+    exp = g["%s_%s" % (problem, method)][level - 1]
+    assert abs(err - exp) <= g["rtol"] * exp, (err, exp)
+    assert abs(err - exp) <= 1e-10 * exp
+
+
 @pytest.mark.parametrize("hyper", [False, True])
 def test_sphere_diffusion_matches_reference_error(oracle, hyper):
     law, grid, dt = diffusion_sphere_setup(1, hyper)
