@@ -36,6 +36,12 @@ int check(cmdg_handle slow, cmdg_handle fast, const cmdg_ocean_coupling_desc *d)
 {
     if (!slow || !fast || !d) return CMDG_ERR_INVALID;
     EngineBase *s = slow->eng, *f = fast->eng;
+    // the flow deviation u_d of ghost columns would have to be integrated from the received
+    // face pencils (as update_auxiliary_state! on ghost elements does); not built yet
+    if (s->communicate() || f->communicate())
+        return s->fail(CMDG_ERR_UNSUPPORTED,
+                       "ocean coupling: partitioned (multi-rank) grids are not supported; run the "
+                       "split-explicit ocean on one rank per column set without ghost elements");
     if (!s->stacked || d->nvertelem < 1 || s->nreal % d->nvertelem)
         return s->fail(CMDG_ERR_INVALID, "ocean coupling: slow grid is not stacked by nvertelem");
     if (f->nreal != s->nreal / d->nvertelem)
