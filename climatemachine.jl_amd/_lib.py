@@ -43,6 +43,7 @@ class CmdgDesc(C.Structure):
         ("nabrtovmapsend", C.c_void_p), ("nabrtovmaprecv", C.c_void_p),
         ("state_auxiliary", C.c_void_p), ("state_gradient_flux", C.c_void_p),
         ("Qhypervisc_grad", C.c_void_p), ("Qhypervisc_div", C.c_void_p),
+        ("Dv", C.c_void_p),
     ]
 
 

@@ -86,6 +86,7 @@ EngineBase::~EngineBase()
     if (d_elemred) hipFree(d_elemred);
     if (d_Imat) hipFree(d_Imat);
     if (d_flowint) hipFree(d_flowint);
+    if (d_Dv) hipFree(d_Dv);
     if (ev_comp) hipEventDestroy(ev_comp);
     if (nccl_comm && rccl::CommDestroy) rccl::CommDestroy(nccl_comm);
     if (s_comp) hipStreamDestroy(s_comp);
@@ -94,8 +95,12 @@ EngineBase::~EngineBase()
 
 int EngineBase::init(const cmdg_desc *d)
 {
-    Np = NQ * NQ * NQ;
-    Nfp = NQ * NQ;
+    Np = NQ * NQ * NQV;
+    Nfp = NQ * (NQ > NQV ? NQ : NQV);  // Nfp_max, the stride of the face tables
+    if (d->N[0] != d->N[1] || d->N[0] != NQ - 1 || d->N[2] != NQV - 1)
+        return fail(CMDG_ERR_INVALID, "cmdg_create: polynomial orders do not match the engine");
+    if (NQV != NQ && !d->Dv)
+        return fail(CMDG_ERR_INVALID, "cmdg_create: Dv is required when the vertical order differs");
     nreal = d->nreal;
     nghost = d->nghost;
     nelem = nreal + nghost;
@@ -144,6 +149,12 @@ int EngineBase::init(const cmdg_desc *d)
     HIPCHK(hipMalloc(&d_D, sizeof(double) * NQ * NQ));
     HIPCHK(hipMemcpy(d_D, d->D, sizeof(double) * NQ * NQ, hipMemcpyHostToDevice));
     g.D = d_D;
+    g.Dv = d_D;
+    if (NQV != NQ) {
+        HIPCHK(hipMalloc(&d_Dv, sizeof(double) * NQV * NQV));
+        HIPCHK(hipMemcpy(d_Dv, d->Dv, sizeof(double) * NQV * NQV, hipMemcpyHostToDevice));
+        g.Dv = d_Dv;
+    }
     aux = d->state_auxiliary;
     const size_t nd = (size_t)Np * nelem;
     auto alloc0 = [&](double **p, size_t n) -> int {
@@ -510,7 +521,8 @@ int EngineBase::stack_integral(bool reverse, const double *Q, int nstate, double
                                int naux_arr, int nvert, const double *Imat_host,
                                const cmdg_stack_integral_desc *d, int64_t h0, int64_t nh)
 {
-    if (NQ < 2 || NQ > 8) return fail(CMDG_ERR_UNSUPPORTED, "stack integral: polynomial order not compiled in");
+    if (NQ < 2 || NQ > 8 || NQV != NQ)
+        return fail(CMDG_ERR_UNSUPPORTED, "stack integral: polynomial order not compiled in");
     if (!stacked) return fail(CMDG_ERR_INVALID, "stack integral: the topology is not stacked");
     if (nvert < 1 || nreal % nvert != 0)
         return fail(CMDG_ERR_INVALID, "stack integral: nreal is not a multiple of nvertelem");
@@ -759,7 +771,8 @@ static void launch_filter_nq(int NQ, const FilterObj *f, const FilterArgs &a, in
 int EngineBase::filter_apply(const FilterObj *f, double *Q, int nstate)
 {
     if (!f || !Q) return fail(CMDG_ERR_INVALID, "filter: NULL argument");
-    if (NQ < 2 || NQ > 8) return fail(CMDG_ERR_UNSUPPORTED, "filter: polynomial order not compiled in");
+    if (NQ < 2 || NQ > 8 || NQV != NQ)
+        return fail(CMDG_ERR_UNSUPPORTED, "filter: polynomial order not compiled in");
     if (nreal <= 0) return CMDG_OK;
     FilterArgs a{};
     a.Q = Q;
@@ -879,8 +892,8 @@ int cmdg_create(const cmdg_desc *d, cmdg_handle *out)
         g_create_err = "no HIP device visible";
         return CMDG_ERR_NO_DEVICE;
     }
-    if (d->dim != 3 || d->N[0] != d->N[1] || d->N[1] != d->N[2]) {
-        g_create_err = "only dim == 3 with one polynomial order is compiled in";
+    if (d->dim != 3 || d->N[0] != d->N[1]) {
+        g_create_err = "only dim == 3 with one horizontal polynomial order is compiled in";
         return CMDG_ERR_UNSUPPORTED;
     }
     std::string err;

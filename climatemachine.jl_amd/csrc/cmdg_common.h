@@ -18,16 +18,36 @@ constexpr int NXCD = 8;
 struct GridDev {
     const double *vgeo, *sgeo;
     const int64_t *vmapM, *vmapP, *elemtobndy;
-    const double *D;  // device, (Nq, Nq) column-major
+    const double *D;   // device, (Nq, Nq) column-major, horizontal
+    const double *Dv;  // device, (Nqv, Nqv) column-major, vertical (== D for one order)
     int nvgeo;
 };
 
-template <int NQ>
+// NQ = horizontal points per direction, NQV = vertical ones (polynomialorder = (N_h, N_v);
+// reference: `info.Nq`, `info.Nqk`, `Nfp_h`, `Nfp_v` of basic_grid_info, SpaceDiscretization.jl:18-60)
+template <int NQ, int NQV = NQ>
 struct KDims {
-    static constexpr int Np = NQ * NQ * NQ;
-    static constexpr int Nfp = NQ * NQ;
-    static constexpr int NFT = 6 * Nfp;  // face-node tasks per element
+    static constexpr int Nij = NQ * NQ;
+    static constexpr int Np = NQ * NQ * NQV;
+    static constexpr int Nfph = NQ * NQV;  // faces 1..4
+    static constexpr int Nfpv = NQ * NQ;   // faces 5, 6
+    // stride of the face tables: sgeo / vmap are (Nfp_max, nface, nelem) (Metrics.jl:485-488)
+    static constexpr int Nfp = Nfph > Nfpv ? Nfph : Nfpv;
+    static constexpr int NFT = 4 * Nfph + 2 * Nfpv;  // face-node tasks per element
     static constexpr int NT = (((Np > NFT ? Np : NFT) + 63) / 64) * 64;
+    __device__ __forceinline__ static void face_task(int t, int &f, int &n)
+    {
+        if constexpr (NQ == NQV) {
+            f = t / Nfp;
+            n = t % Nfp;
+        } else if (t < 4 * Nfph) {
+            f = t / Nfph;
+            n = t % Nfph;
+        } else {
+            f = 4 + (t - 4 * Nfph) / Nfpv;
+            n = (t - 4 * Nfph) % Nfpv;
+        }
+    }
 };
 
 // Blocks b and b+8 share an XCD (and its L2); hand each XCD a contiguous run of the

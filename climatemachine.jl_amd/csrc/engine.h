@@ -52,7 +52,7 @@ struct ProfRec {
 
 struct EngineBase {
     // ---- configuration (copied from cmdg_desc) ---------------------------------------
-    int NQ = 0, Np = 0, Nfp = 0;
+    int NQ = 0, NQV = 0, Np = 0, Nfp = 0;  // horizontal / vertical points per direction
     int64_t nreal = 0, nghost = 0, nelem = 0;
     int ns = 0, naux = 0, ngrad = 0, ngf = 0, ngl = 0, nhyp = 0;
     int nf_first = 0, direction = 0, diffusion_direction = 0, stacked = 0;
@@ -133,6 +133,7 @@ struct EngineBase {
     double *d_flowint = nullptr;  // (Np, 2, nelem) column integral of the horizontal velocity
     int run_gradient_hooks(const RhsCtx &c, int64_t e0, int64_t e1);
     double *d_Imat = nullptr;
+    double *d_Dv = nullptr;  // vertical derivative matrix when the vertical order differs
     int filter_create(const cmdg_filter_desc *d, FilterObj **out);
     int filter_apply(const FilterObj *f, double *Q, int nstate);
 
@@ -156,7 +157,7 @@ int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, doubl
                     int nstages, const double *rka, const double *rkb, const double *rkc);
 
 // ---------------------------------------------------------------------------------
-template <class P, int NQ_>
+template <class P, int NQ_, int NQV_ = NQ_>
 struct EngineT : EngineBase {
     typename P::Params prm;
     PassArgs<P> make_args(const RhsCtx &c, const int64_t *elems, int64_t n, int dir) const
@@ -189,7 +190,7 @@ struct EngineT : EngineBase {
     {
         if (n <= 0) return;
         prof_begin(CMDG_K_GRADIENTS, s_comp);
-        hipLaunchKernelGGL((k_gradients<P, NQ_>), dim3((unsigned)n), dim3(KDims<NQ_>::NT), 0,
+        hipLaunchKernelGGL((k_gradients<P, NQ_, NQV_>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0,
                            s_comp, make_args(c, elems, n, diffusion_direction));
         prof_end(s_comp);
     }
@@ -197,7 +198,7 @@ struct EngineT : EngineBase {
     {
         if (n <= 0) return;
         prof_begin(CMDG_K_DIVGRAD, s_comp);
-        hipLaunchKernelGGL((k_divgrad<P, NQ_>), dim3((unsigned)n), dim3(KDims<NQ_>::NT), 0, s_comp,
+        hipLaunchKernelGGL((k_divgrad<P, NQ_, NQV_>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0, s_comp,
                            make_args(c, elems, n, diffusion_direction));
         prof_end(s_comp);
     }
@@ -205,7 +206,7 @@ struct EngineT : EngineBase {
     {
         if (n <= 0) return;
         prof_begin(CMDG_K_GRADLAP, s_comp);
-        hipLaunchKernelGGL((k_gradlap<P, NQ_>), dim3((unsigned)n), dim3(KDims<NQ_>::NT), 0, s_comp,
+        hipLaunchKernelGGL((k_gradlap<P, NQ_, NQV_>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0, s_comp,
                            make_args(c, elems, n, diffusion_direction));
         prof_end(s_comp);
     }
@@ -218,18 +219,18 @@ struct EngineT : EngineBase {
 #else
         const bool gfl = P::needs_gradflux(prm);
 #endif
-        const dim3 grid((unsigned)n), block(KDims<NQ_>::NT);
+        const dim3 grid((unsigned)n), block(KDims<NQ_, NQV_>::NT);
         const PassArgs<P> args = make_args(c, elems, n, direction);
         if (c.lsrk) {
             if (gfl)
-                hipLaunchKernelGGL((k_tendency<P, NQ_, true, true>), grid, block, 0, s_comp, args);
+                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, true, true>), grid, block, 0, s_comp, args);
             else
-                hipLaunchKernelGGL((k_tendency<P, NQ_, true, false>), grid, block, 0, s_comp, args);
+                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, true, false>), grid, block, 0, s_comp, args);
         } else {
             if (gfl)
-                hipLaunchKernelGGL((k_tendency<P, NQ_, false, true>), grid, block, 0, s_comp, args);
+                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, false, true>), grid, block, 0, s_comp, args);
             else
-                hipLaunchKernelGGL((k_tendency<P, NQ_, false, false>), grid, block, 0, s_comp, args);
+                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, false, false>), grid, block, 0, s_comp, args);
         }
         prof_end(s_comp);
     }
@@ -237,9 +238,9 @@ struct EngineT : EngineBase {
     {
         if constexpr (P::HAS_UPDATE_AUX) {
             if (e1 <= e0 || !P::update_aux_active(prm)) return;
-            const int64_t n = (e1 - e0) * KDims<NQ_>::Np;
+            const int64_t n = (e1 - e0) * KDims<NQ_, NQV_>::Np;
             prof_begin(CMDG_K_UPDATE_AUX, s_comp);
-            hipLaunchKernelGGL((k_update_aux<P, NQ_>), dim3((unsigned)((n + 255) / 256)), dim3(256),
+            hipLaunchKernelGGL((k_update_aux<P, NQ_, NQV_>), dim3((unsigned)((n + 255) / 256)), dim3(256),
                                0, s_comp, prm, c.Qin, aux, d_activedofs, c.t, e0, e1);
             prof_end(s_comp);
         }
@@ -247,14 +248,14 @@ struct EngineT : EngineBase {
     int launch_courant(int mode, int kind, const double *Q, double dt, double t, int dir,
                        double *out_elem) override
     {
-        constexpr int NT = KDims<NQ_>::Np <= 128 ? 128 : 256;
+        constexpr int NT = KDims<NQ_, NQV_>::Np <= 128 ? 128 : 256;
         if (mode == 1 && !P::HAS_COURANT)
             return fail(CMDG_ERR_UNSUPPORTED, "this balance law defines no local Courant number");
         if (mode == 0)
-            hipLaunchKernelGGL((k_courant<P, NQ_, 0>), dim3((unsigned)nreal), dim3(NT), 0, s_comp, prm,
+            hipLaunchKernelGGL((k_courant<P, NQ_, NQV_, 0>), dim3((unsigned)nreal), dim3(NT), 0, s_comp, prm,
                                g.vgeo, g.nvgeo, Q, aux, gf, kind, dt, t, dir, out_elem);
         else
-            hipLaunchKernelGGL((k_courant<P, NQ_, 1>), dim3((unsigned)nreal), dim3(NT), 0, s_comp, prm,
+            hipLaunchKernelGGL((k_courant<P, NQ_, NQV_, 1>), dim3((unsigned)nreal), dim3(NT), 0, s_comp, prm,
                                g.vgeo, g.nvgeo, Q, aux, gf, kind, dt, t, dir, out_elem);
         return CMDG_OK;
     }
@@ -263,10 +264,10 @@ struct EngineT : EngineBase {
     int init_derived() override
     {
         if constexpr (P::NDER > 0) {
-            const int64_t n = nelem * KDims<NQ_>::Np;
+            const int64_t n = nelem * KDims<NQ_, NQV_>::Np;
             if (hipMalloc(&derived, sizeof(double) * n * P::NDER) != hipSuccess)
                 return fail(CMDG_ERR_HIP, "hipMalloc(derived) failed");
-            hipLaunchKernelGGL((k_init_derived<P, NQ_>), dim3((unsigned)((n + 255) / 256)), dim3(256),
+            hipLaunchKernelGGL((k_init_derived<P, NQ_, NQV_>), dim3((unsigned)((n + 255) / 256)), dim3(256),
                                0, s_comp, prm, aux, derived, nelem);
             if (hipStreamSynchronize(s_comp) != hipSuccess)
                 return fail(CMDG_ERR_HIP, "k_init_derived failed");
@@ -275,11 +276,12 @@ struct EngineT : EngineBase {
     }
 };
 
-template <class P, int NQ_>
+template <class P, int NQ_, int NQV_ = NQ_>
 EngineBase *make_engine(const cmdg_desc *d)
 {
-    auto *e = new EngineT<P, NQ_>();
+    auto *e = new EngineT<P, NQ_, NQV_>();
     e->NQ = NQ_;
+    e->NQV = NQV_;
     e->ns = P::NS;
     e->naux = P::NAUX;
     e->ngrad = P::NGRAD;

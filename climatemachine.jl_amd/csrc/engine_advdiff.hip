@@ -36,6 +36,17 @@ EngineBase *make_engine_advdiff(const cmdg_desc *d, std::string &err)
         err = "AdvectionDiffusion: num_equations != 1 is not compiled in";
         return nullptr;
     }
+    if (d->N[2] != d->N[0]) {
+        // polynomialorder = (N_h, N_v): the pairs of variable_degree_advection_diffusion.jl:300
+        const bool adv = d->iparam[1], diff = d->iparam[2], hyp = d->iparam[3];
+        if (adv && diff && !hyp) {
+            if (d->N[0] == 4 && d->N[2] == 2) return make_engine<AdvDiff<true, true, false>, 5, 3>(d);
+            if (d->N[0] == 2 && d->N[2] == 4) return make_engine<AdvDiff<true, true, false>, 3, 5>(d);
+        }
+        err = "AdvectionDiffusion: mixed polynomial orders compiled in are (4,2) and (2,4), "
+              "advection + diffusion";
+        return nullptr;
+    }
     switch (d->N[0]) {  // NQ = N + 1 is a template parameter of every kernel
     case 1: return pick<2>(d, err);
     case 2: return pick<3>(d, err);

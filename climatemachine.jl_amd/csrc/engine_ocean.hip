@@ -48,6 +48,13 @@ EngineBase *make_engine_sw(const cmdg_desc *d, std::string &err)
         err = "ShallowWaterModel: LinearDrag is not compiled in (ConstantViscosity only)";
         return nullptr;
     }
+    if (d->N[2] != d->N[0]) {
+        // the one-layer extrusion of the 2-D grid needs no resolution along the extrusion:
+        // two nodes (N_v = 1) carry the same 2-D arithmetic at 2/5 of the work
+        if (d->N[0] == 4 && d->N[2] == 1) return make_engine<ShallowWater, 5, 2>(d);
+        err = "ShallowWaterModel: mixed polynomial orders compiled in: (4, 1)";
+        return nullptr;
+    }
     switch (d->N[0]) {
     case 2: return make_engine<ShallowWater, 3>(d);
     case 3: return make_engine<ShallowWater, 4>(d);

@@ -62,21 +62,21 @@ struct FacePt {
 
 // index half of face_setup: issued at kernel start so that the plus-side gathers do not wait
 // for a dependent table load when the interface phase begins
-template <int NQ>
+template <int NQ, int NQV = NQ>
 __device__ __forceinline__ void face_index(const GridDev &g, int64_t e, int f, int n, int64_t &idM,
                                            int64_t &idP, int &bctag)
 {
-    constexpr int Nfp = KDims<NQ>::Nfp;
+    constexpr int Nfp = KDims<NQ, NQV>::Nfp;
     const int64_t o = n + (int64_t)Nfp * (f + 6 * e);
     idM = g.vmapM[o];
     idP = g.vmapP[o];
     bctag = (int)g.elemtobndy[f + 6 * e];
 }
-template <int NQ>
+template <int NQ, int NQV = NQ>
 __device__ __forceinline__ void face_geometry(const GridDev &g, int64_t e, int f, int n,
                                               int64_t idM, int64_t idP, int bctag, FacePt &fp)
 {
-    constexpr int Np = KDims<NQ>::Np, Nfp = KDims<NQ>::Nfp;
+    constexpr int Np = KDims<NQ, NQV>::Np, Nfp = KDims<NQ, NQV>::Nfp;
     const int64_t o = n + (int64_t)Nfp * (f + 6 * e);
     const double *sg = g.sgeo + 5 * o;
     fp.n[0] = sg[SN1];
@@ -93,10 +93,10 @@ __device__ __forceinline__ void face_geometry(const GridDev &g, int64_t e, int f
         fp.vidP = fp.vidM;
     }
 }
-template <int NQ>
+template <int NQ, int NQV = NQ>
 __device__ __forceinline__ void face_setup(const GridDev &g, int64_t e, int f, int n, FacePt &fp)
 {
-    constexpr int Np = KDims<NQ>::Np, Nfp = KDims<NQ>::Nfp;
+    constexpr int Np = KDims<NQ, NQV>::Np, Nfp = KDims<NQ, NQV>::Nfp;
     const int64_t o = n + (int64_t)Nfp * (f + 6 * e);
     const double *sg = g.sgeo + 5 * o;
     fp.n[0] = sg[SN1];
@@ -153,44 +153,50 @@ __device__ __forceinline__ void nf_first_order(const typename P::Params &prm, in
 // ---------------------------------------------------------------------------------
 // Index of a surface node among the element's surface nodes (-1: interior node).  The
 // minus-side face data of the interface phases is staged in LDS for surface nodes only.
-template <int NQ>
+template <int NQ, int NQV = NQ>
 __device__ __forceinline__ int surf_index(int ijk)
 {
-    constexpr int NI = NQ - 2;
+    constexpr int NI = NQ - 2, NIV = NQV > 2 ? NQV - 2 : 0;
     const int i = ijk % NQ, j = (ijk / NQ) % NQ, k = ijk / (NQ * NQ);
-    const bool ii = i >= 1 && i <= NI, jj = j >= 1 && j <= NI, kk = k >= 1 && k <= NI;
+    const bool ii = i >= 1 && i <= NI, jj = j >= 1 && j <= NI, kk = k >= 1 && k <= NIV;
     if (ii && jj && kk) return -1;
-    auto clampi = [](int v) { return v < 0 ? 0 : (v > NI ? NI : v); };
-    int before = NI * NI * clampi(k - 1);
+    auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    int before = NI * NI * clampi(k - 1, NIV);
     if (kk) {
-        before += NI * clampi(j - 1);
-        if (jj) before += clampi(i - 1);
+        before += NI * clampi(j - 1, NI);
+        if (jj) before += clampi(i - 1, NI);
     }
     return ijk - before;
 }
-template <int NQ>
+template <int NQ, int NQV = NQ>
 struct SurfDims {
-    static constexpr int NSURF = NQ * NQ * NQ - (NQ - 2) * (NQ - 2) * (NQ - 2);
+    static constexpr int NSURF =
+        NQ * NQ * NQV - (NQ - 2) * (NQ - 2) * (NQV > 2 ? NQV - 2 : 0);
 };
 
 // ---------------------------------------------------------------------------------
 // Tendency pass: volume_tendency! (:64-548) + dgsem_interface_tendency! (:588-901),
 // optionally fused with the LSRK update! (LowStorageRungeKuttaMethod.jl:146-158).
-template <class P, int NQ, bool LSRK, bool USE_GF>
-__global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(const PassArgs<P> a)
+template <class P, int NQ, int NQV, bool LSRK, bool USE_GF>
+__global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tendency(const PassArgs<P> a)
 {
-    using KD = KDims<NQ>;
-    constexpr int Np = KD::Np, Nfp = KD::Nfp, NS = P::NS, NAUX = P::NAUX, NGF = P::NGF,
+    using KD = KDims<NQ, NQV>;
+    constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGF = P::NGF,
                   NHYP = P::NHYP, NHG = 3 * P::NGL, NFA = P::NFAUX,
-                  NSURF = SurfDims<NQ>::NSURF, NGFS = USE_GF ? NGF : 0,
+                  NSURF = SurfDims<NQ, NQV>::NSURF, NGFS = USE_GF ? NGF : 0,
                   NMF = NS + NFA + NGFS + NHYP;
     __shared__ double sD[NQ * NQ];
+    __shared__ double sDv_[NQV == NQ ? 1 : NQV * NQV];
+    const double *const sDv = NQV == NQ ? sD : sDv_;  // vertical derivative matrix
     __shared__ double sF[3 * NS * Np];  // contravariant flux [d][s][ijk]; later the accumulator
     __shared__ double sM[NMF * NSURF];  // minus-side state of the surface nodes [field][sidx]
     double *const sT = sF;              // tendency accumulator [s][ijk] (aliases sF after phase 2)
     const int tid = threadIdx.x;
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
     if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
+    if constexpr (NQV != NQ) {
+        if (tid < NQV * NQV) sDv_[tid] = a.g.Dv[tid];
+    }
     const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
     // USE_GF: does flux_second_order depend on the gradient-flux state at all?  With zero
     // viscosity (Held-Suarez) tau = -2*0*S and D_t = 0: the 9 fields only ever multiply
@@ -198,8 +204,10 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
     constexpr bool use_gf = NGF > 0 && USE_GF;
     int64_t f_idM = 1, f_idP = 1;
     int f_bctag = 0;
-    const bool face_on = tid < KD::NFT && ((tid / Nfp) < 4 ? hz : vt);
-    if (face_on) face_index<NQ>(a.g, e, tid / Nfp, tid % Nfp, f_idM, f_idP, f_bctag);
+    int f_f = 0, f_n = 0;
+    KD::face_task(tid, f_f, f_n);
+    const bool face_on = tid < KD::NFT && (f_f < 4 ? hz : vt);
+    if (face_on) face_index<NQ, NQV>(a.g, e, f_f, f_n, f_idM, f_idP, f_bctag);
     Vec<NS> S;
     double MI = 0;
     if (tid < Np) {
@@ -218,7 +226,7 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
 #pragma unroll
         for (int s = 0; s < NHYP; ++s)
             lhyp[s] = a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)];
-        const int sidx = surf_index<NQ>(tid);
+        const int sidx = surf_index<NQ, NQV>(tid);
         if (sidx >= 0) {  // stage the minus side of the interface phase
 #pragma unroll
             for (int s = 0; s < NS; ++s) sM[s * NSURF + sidx] = lQ[s];
@@ -288,8 +296,8 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
                        // horizontal call in EveryDirection (SpaceDiscretization.jl:1192)
                 double lt = 0.0;
 #pragma unroll
-                for (int kk = 0; kk < NQ; ++kk) {
-                    lt += MI * sD[kk + NQ * k] * sF[(2 * NS + s) * Np + i + NQ * (j + NQ * kk)];
+                for (int kk = 0; kk < NQV; ++kk) {
+                    lt += MI * sDv[kk + NQV * k] * sF[(2 * NS + s) * Np + i + NQ * (j + NQ * kk)];
                     if (kk == k && P::HAS_SOURCE) lt += S[s];
                 }
                 if (hz)
@@ -313,16 +321,16 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
 #else
     if (tid < KD::NFT) {
 #endif
-        const int f = tid / Nfp, n = tid % Nfp;
+        const int f = f_f, n = f_n;
         if (face_on) {
             const int facedir = f < 4 ? DIR_HORIZONTAL : DIR_VERTICAL;
             FacePt fp;
-            face_geometry<NQ>(a.g, e, f, n, f_idM, f_idP, f_bctag, fp);
+            face_geometry<NQ, NQV>(a.g, e, f, n, f_idM, f_idP, f_bctag, fp);
             Vec<NS> QM, QPn, QPd, flux;
             Vec<NAUX> auxM, auxPn, auxPd;
             Vec<NGF> gfM, gfP;
             Vec<NHYP> hypM, hypP;
-            const int sidx = surf_index<NQ>(fp.vidM);
+            const int sidx = surf_index<NQ, NQV>(fp.vidM);
 #pragma unroll
             for (int s = 0; s < NAUX; ++s) auxM[s] = 0;
 #pragma unroll
@@ -432,18 +440,23 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_TEND_MINW) k_tendency(cons
 
 // ---------------------------------------------------------------------------------
 // Gradient pass: volume_gradients! (:934-1328) + dgsem_interface_gradients! (:1365-1651)
-template <class P, int NQ>
-__global__ void __launch_bounds__(KDims<NQ>::NT, (NQ == 5 ? CMDG_GRAD_MINW : 1)) k_gradients(const PassArgs<P> a)
+template <class P, int NQ, int NQV = NQ>
+__global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? CMDG_GRAD_MINW : 1)) k_gradients(const PassArgs<P> a)
 {
-    using KD = KDims<NQ>;
-    constexpr int Np = KD::Np, Nfp = KD::Nfp, NS = P::NS, NAUX = P::NAUX, NGRAD = P::NGRAD,
+    using KD = KDims<NQ, NQV>;
+    constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGRAD = P::NGRAD,
                   NGF = P::NGF, NGL = P::NGL, NHG = 3 * NGL, NACC = NGF + NHG;
     __shared__ double sD[NQ * NQ];
+    __shared__ double sDv_[NQV == NQ ? 1 : NQV * NQV];
+    const double *const sDv = NQV == NQ ? sD : sDv_;  // vertical derivative matrix
     __shared__ double sG[(NGRAD > 0 ? NGRAD : 1) * Np];
     __shared__ double sA[(NACC > 0 ? NACC : 1) * Np];  // [gf..., hypgrad...][ijk]
     const int tid = threadIdx.x;
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
     if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
+    if constexpr (NQV != NQ) {
+        if (tid < NQV * NQV) sDv_[tid] = a.g.Dv[tid];
+    }
     const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
     Vec<NS> lQ;
     Vec<NAUX> laux;
@@ -497,8 +510,8 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, (NQ == 5 ? CMDG_GRAD_MINW : 1))
             for (int s = 0; s < NGRAD; ++s) {
                 double G3 = -0.0;
 #pragma unroll
-                for (int n = 0; n < NQ; ++n)
-                    G3 += sD[k + NQ * n] * sG[s * Np + i + NQ * (j + NQ * n)];
+                for (int n = 0; n < NQV; ++n)
+                    G3 += sDv[k + NQV * n] * sG[s * Np + i + NQ * (j + NQ * n)];
                 gv[3 * s + 0] += x31 * G3;
                 gv[3 * s + 1] += x32 * G3;
                 gv[3 * s + 2] += x33 * G3;
@@ -527,11 +540,12 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, (NQ == 5 ? CMDG_GRAD_MINW : 1))
     Vec<NACC> corr;
     int vidM = 0, fpair = -1;
     if (tid < KD::NFT) {
-        const int f = tid / Nfp, n = tid % Nfp;
+        int f, n;
+        KD::face_task(tid, f, n);
         const bool on = f < 4 ? hz : vt;
         if (on) {
             FacePt fp;
-            face_setup<NQ>(a.g, e, f, n, fp);
+            face_setup<NQ, NQV>(a.g, e, f, n, fp);
             Vec<NS> QM, QP;
             Vec<NAUX> auxM, auxP;
             Vec<NGRAD> GM, GP;
@@ -612,20 +626,25 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, (NQ == 5 ? CMDG_GRAD_MINW : 1))
 // ---------------------------------------------------------------------------------
 // Laplacian pass: volume_divergence_of_gradients! (:2132-2329) +
 // interface_divergence_of_gradients! (:2360-2494)
-template <class P, int NQ>
-__global__ void __launch_bounds__(KDims<NQ>::NT) k_divgrad(const PassArgs<P> a)
+template <class P, int NQ, int NQV = NQ>
+__global__ void __launch_bounds__((KDims<NQ, NQV>::NT)) k_divgrad(const PassArgs<P> a)
 {
-    using KD = KDims<NQ>;
-    constexpr int Np = KD::Np, Nfp = KD::Nfp, NAUX = P::NAUX, NGL = P::NGL, NHG = 3 * NGL,
+    using KD = KDims<NQ, NQV>;
+    constexpr int Np = KD::Np, NAUX = P::NAUX, NGL = P::NGL, NHG = 3 * NGL,
                   NHYP = P::NHYP, NG = NGL > 0 ? NGL : 1;
     __shared__ double sD[NQ * NQ];
+    __shared__ double sDv_[NQV == NQ ? 1 : NQV * NQV];
+    const double *const sDv = NQV == NQ ? sD : sDv_;  // vertical derivative matrix
     __shared__ double sC[3 * NG * Np];  // M * (xi_d . grad) [d][s][ijk]
     __shared__ double sA[NG * Np];
-    constexpr int NSURF = SurfDims<NQ>::NSURF;
+    constexpr int NSURF = SurfDims<NQ, NQV>::NSURF;
     __shared__ double sM[(NHG > 0 ? NHG : 1) * NSURF];  // minus-side gradients, surface nodes
     const int tid = threadIdx.x;
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
     if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
+    if constexpr (NQV != NQ) {
+        if (tid < NQV * NQV) sDv_[tid] = a.g.Dv[tid];
+    }
     const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
     double MI = 0;
     if (tid < Np) {
@@ -643,7 +662,7 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_divgrad(const PassArgs<P> a)
             sC[(0 * NG + s) * Np + tid] = M * (x11 * G1 + x12 * G2 + x13 * G3);
             sC[(1 * NG + s) * Np + tid] = M * (x21 * G1 + x22 * G2 + x23 * G3);
             sC[(2 * NG + s) * Np + tid] = M * (x31 * G1 + x32 * G2 + x33 * G3);
-            const int sidx = surf_index<NQ>(tid);
+            const int sidx = surf_index<NQ, NQV>(tid);
             if (sidx >= 0) {
                 sM[(3 * s + 0) * NSURF + sidx] = G1;
                 sM[(3 * s + 1) * NSURF + sidx] = G2;
@@ -666,8 +685,8 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_divgrad(const PassArgs<P> a)
             }
             if (vt) {
 #pragma unroll
-                for (int kk = 0; kk < NQ; ++kk)
-                    dv -= MI * sD[kk + NQ * k] * sC[(2 * NG + s) * Np + i + NQ * (j + NQ * kk)];
+                for (int kk = 0; kk < NQV; ++kk)
+                    dv -= MI * sDv[kk + NQV * k] * sC[(2 * NG + s) * Np + i + NQ * (j + NQ * kk)];
             }
             sA[s * Np + tid] = hz ? (vt ? dh + dv : dh) : dv;
         }
@@ -676,13 +695,14 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_divgrad(const PassArgs<P> a)
     Vec<NGL> corr;
     int vidM = 0, fpair = -1;
     if (tid < KD::NFT) {
-        const int f = tid / Nfp, n = tid % Nfp;
+        int f, n;
+        KD::face_task(tid, f, n);
         const bool on = f < 4 ? hz : vt;
         if (on) {
             FacePt fp;
-            face_setup<NQ>(a.g, e, f, n, fp);
+            face_setup<NQ, NQV>(a.g, e, f, n, fp);
             Vec<NHG> gM, gP;
-            const int sidx = surf_index<NQ>(fp.vidM);
+            const int sidx = surf_index<NQ, NQV>(fp.vidM);
 #pragma unroll
             for (int q = 0; q < NHG; ++q) {
                 gM[q] = sM[q * NSURF + sidx];
@@ -725,19 +745,24 @@ __global__ void __launch_bounds__(KDims<NQ>::NT) k_divgrad(const PassArgs<P> a)
 // ---------------------------------------------------------------------------------
 // Gradient-of-Laplacian pass: volume_gradients_of_laplacians! (:2525-2824) +
 // interface_gradients_of_laplacians! (:2859-3026)
-template <class P, int NQ>
-__global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_LAP_MINW) k_gradlap(const PassArgs<P> a)
+template <class P, int NQ, int NQV = NQ>
+__global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_LAP_MINW) k_gradlap(const PassArgs<P> a)
 {
-    using KD = KDims<NQ>;
-    constexpr int Np = KD::Np, Nfp = KD::Nfp, NS = P::NS, NAUX = P::NAUX, NGL = P::NGL,
+    using KD = KDims<NQ, NQV>;
+    constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGL = P::NGL,
                   NHG = 3 * NGL, NHYP = P::NHYP, NG = NGL > 0 ? NGL : 1,
                   NH = NHYP > 0 ? NHYP : 1;
     __shared__ double sD[NQ * NQ];
+    __shared__ double sDv_[NQV == NQ ? 1 : NQV * NQV];
+    const double *const sDv = NQV == NQ ? sD : sDv_;  // vertical derivative matrix
     __shared__ double sL[NG * Np];
     __shared__ double sA[NH * Np];
     const int tid = threadIdx.x;
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
     if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
+    if constexpr (NQV != NQ) {
+        if (tid < NQV * NQV) sDv_[tid] = a.g.Dv[tid];
+    }
     const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
     if (tid < Np) {
 #pragma unroll
@@ -780,8 +805,8 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_LAP_MINW) k_gradlap(const 
             for (int s = 0; s < NGL; ++s) {
                 double l3 = -0.0;
 #pragma unroll
-                for (int n = 0; n < NQ; ++n)
-                    l3 += sD[k + NQ * n] * sL[s * Np + i + NQ * (j + NQ * n)];
+                for (int n = 0; n < NQV; ++n)
+                    l3 += sDv[k + NQV * n] * sL[s * Np + i + NQ * (j + NQ * n)];
                 lv[3 * s + 0] += x31 * l3;
                 lv[3 * s + 1] += x32 * l3;
                 lv[3 * s + 2] += x33 * l3;
@@ -799,11 +824,12 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_LAP_MINW) k_gradlap(const 
     Vec<NHYP> corr;
     int vidM = 0, fpair = -1;
     if (tid < KD::NFT) {
-        const int f = tid / Nfp, n = tid % Nfp;
+        int f, n;
+        KD::face_task(tid, f, n);
         const bool on = f < 4 ? hz : vt;
         if (on) {
             FacePt fp;
-            face_setup<NQ>(a.g, e, f, n, fp);
+            face_setup<NQ, NQV>(a.g, e, f, n, fp);
             Vec<NS> QM, QP;
             Vec<NAUX> auxM, auxP;
             Vec<NGL> lapM, lapP;
@@ -851,11 +877,11 @@ __global__ void __launch_bounds__(KDims<NQ>::NT, CMDG_LAP_MINW) k_gradlap(const 
 
 // ---------------------------------------------------------------------------------
 // kernel_nodal_update_auxiliary_state!  (:1769-1825); elements [e0, e1)
-template <class P, int NQ>
+template <class P, int NQ, int NQV = NQ>
 __global__ void k_update_aux(typename P::Params prm, const double *Q, double *aux,
                              const uint8_t *activedofs, double t, int64_t e0, int64_t e1)
 {
-    constexpr int Np = KDims<NQ>::Np, NS = P::NS, NAUX = P::NAUX;
+    constexpr int Np = KDims<NQ, NQV>::Np, NS = P::NS, NAUX = P::NAUX;
     const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t e = e0 + I / Np;
     const int n = (int)(I % Np);
@@ -871,11 +897,11 @@ __global__ void k_update_aux(typename P::Params prm, const double *Q, double *au
 }
 
 // one-time: time-invariant per-node fields the law would otherwise recompute every call
-template <class P, int NQ>
+template <class P, int NQ, int NQV = NQ>
 __global__ void k_init_derived(typename P::Params prm, const double *aux, double *derived,
                                int64_t nelem)
 {
-    constexpr int Np = KDims<NQ>::Np, NAUX = P::NAUX, NDER = P::NDER;
+    constexpr int Np = KDims<NQ, NQV>::Np, NAUX = P::NAUX, NDER = P::NDER;
     const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t e = I / Np;
     const int n = (int)(I % Np);
@@ -948,13 +974,13 @@ static __global__ void k_wsum2(const double *__restrict__ A, const double *__res
 // (kernel_min_neighbor_distance!, Grids.jl:1228-1333) and the law's local Courant number
 // (kernel_local_courant!, DGModel_kernels.jl:3028-3096) evaluated per node, then a block-wide
 // extremum.  MODE 0: out[e] = min distance of the element, MODE 1: out[e] = max Courant.
-template <class P, int NQ, int MODE>
-__global__ __launch_bounds__(KDims<NQ>::Np <= 128 ? 128 : 256) void k_courant(
+template <class P, int NQ, int NQV, int MODE>
+__global__ __launch_bounds__((KDims<NQ, NQV>::Np <= 128 ? 128 : 256)) void k_courant(
     typename P::Params prm, const double *__restrict__ vgeo, int nvgeo,
     const double *__restrict__ Q, const double *__restrict__ aux, const double *__restrict__ gf,
     int kind, double dt, double t, int direction, double *__restrict__ out)
 {
-    constexpr int Np = KDims<NQ>::Np, NT = Np <= 128 ? 128 : 256;
+    constexpr int Np = KDims<NQ, NQV>::Np, NT = Np <= 128 ? 128 : 256;
     __shared__ double sx[3][Np], sred[NT];
     const int tid = threadIdx.x;
     const int64_t e = blockIdx.x;
@@ -979,7 +1005,7 @@ __global__ __launch_bounds__(KDims<NQ>::Np <= 128 ? 128 : 256) void k_courant(
         }
         if (direction != DIR_HORIZONTAL) {
             if (k > 0) md = fmin(md, dist(n - NQ * NQ));
-            if (k < NQ - 1) md = fmin(md, dist(n + NQ * NQ));
+            if (k < NQV - 1) md = fmin(md, dist(n + NQ * NQ));
         }
         if constexpr (MODE == 0) {
             val = fmin(val, md);

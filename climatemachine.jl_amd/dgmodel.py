@@ -48,8 +48,8 @@ class DGModel:
         self.direction = direction
         self.diffusion_direction = direction if diffusion_direction is None else diffusion_direction
         law, g = balance_law, grid
-        if g.dim != 3 or len(set(g.N)) != 1:
-            raise _lib.CmdgError("libcmdg: 3-D grids with one polynomial order only")
+        if g.dim != 3 or g.N[0] != g.N[1]:
+            raise _lib.CmdgError("libcmdg: 3-D grids with one horizontal polynomial order only")
         ip, dp = law.descriptor()
         counts = (C.c_int32 * 6)()
         ipa = (C.c_int32 * 16)(*[int(v) for v in ip])
@@ -68,6 +68,7 @@ class DGModel:
         self._exterior = _dev(np.asarray(g.exteriorelems, dtype=np.int64), dev)
         self._active = _dev(g.activedofs.astype(np.uint8), dev)
         self._D = np.ascontiguousarray(g.D[0].T, dtype=np.float64)   # column-major (Nq, Nq)
+        self._Dv = np.ascontiguousarray(g.D[-1].T, dtype=np.float64)  # vertical (Nqv, Nqv)
         self._vmapsend = _dev(np.asarray(g.vmapsend, dtype=np.int64), dev)
         self._vmaprecv = _dev(np.asarray(g.vmaprecv, dtype=np.int64), dev)
         nn = len(g.nabrtorank)
@@ -102,6 +103,7 @@ class DGModel:
         d.exteriorelems, d.nexterior = self._exterior.data_ptr(), self._exterior.numel()
         d.activedofs = self._active.data_ptr()
         d.D = self._D.ctypes.data
+        d.Dv = self._Dv.ctypes.data
         d.vmapsend, d.nvmapsend = self._vmapsend.data_ptr(), self._vmapsend.numel()
         d.vmaprecv, d.nvmaprecv = self._vmaprecv.data_ptr(), self._vmaprecv.numel()
         d.nnabr = nn

@@ -194,17 +194,20 @@ class ShallowWaterModel:
 
 
 def extruded_barotropic_grid(xrange, yrange, N, periodicity=(True, True), boundary=((0, 0), (0, 0)),
-                             connectivity="full", rank=0, size=1):
+                             connectivity="full", rank=0, size=1, N_extrusion=None):
     """One periodic layer of unit height over the horizontal brick mesh ``xrange x yrange``:
     the grid the 2-D barotropic model runs on with the 3-D kernels.  Built by the same stacked
     topology as the 3-D ocean grid, so element ``eh`` of it sits under the stack
-    ``eh * nvert .. (eh + 1) * nvert - 1`` of the 3-D grid."""
+    ``eh * nvert .. (eh + 1) * nvert - 1`` of the 3-D grid.  ``N_extrusion`` is the polynomial
+    order along the extrusion (default ``N``); nothing varies in that direction, so
+    ``N_extrusion = 1`` (two nodes) carries the same 2-D arithmetic at 2/5 of the work."""
     from . import mesh as M
     rng = [np.asarray(xrange), np.asarray(yrange), np.array([0.0, 1.0])]
     topl = M.StackedBrickTopology(rng, periodicity=(periodicity[0], periodicity[1], True),
                                   boundary=(boundary[0], boundary[1], (0, 0)),
                                   connectivity=connectivity, rank=rank, size=size)
-    return M.DiscontinuousSpectralElementGrid(topl, N)
+    Nx = N if N_extrusion is None else int(N_extrusion)
+    return M.DiscontinuousSpectralElementGrid(topl, (N, N, Nx))
 
 
 def install_hydrostatic_boussinesq_hooks(dg, vert_filter=None, exp_filter=None):

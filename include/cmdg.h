@@ -54,7 +54,9 @@ enum {
  * `DiscontinuousSpectralElementGrid` it reads (src/Numerics/Mesh/Grids.jl:187-264). */
 typedef struct cmdg_desc {
     int32_t dim;                 /* 3 */
-    int32_t N[3];                /* polynomial orders; N[0] == N[1] == N[2] */
+    int32_t N[3];                /* polynomial orders (horizontal, horizontal, vertical);
+                                    N[0] == N[1]; N[2] may differ (polynomialorder = (N_h, N_v),
+                                    Grids.jl:187-264) for the combinations compiled in */
     int64_t nreal, nghost;       /* topology.realelems / ghostelems counts */
     int32_t nvgeo;               /* columns of vgeo (25: GeometricFactors.jl:60-67) */
     int32_t physics_id;          /* CMDG_PHYSICS_* */
@@ -89,6 +91,8 @@ typedef struct cmdg_desc {
     double *state_gradient_flux;   /* (Np, ngradflux, nelem) */
     double *Qhypervisc_grad;       /* (Np, 3*ngradlap, nelem)  create_states.jl:22-26 */
     double *Qhypervisc_div;        /* (Np, nhyper, nelem) */
+    const double *Dv;              /* HOST pointer, (Nqv, Nqv) column-major, grid.D[end]; may be
+                                      NULL when N[2] == N[0] */
 } cmdg_desc;
 
 /* ---- queries ------------------------------------------------------------------ */

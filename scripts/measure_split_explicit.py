@@ -24,9 +24,12 @@ dt_slow = (float(sys.argv[3]) if len(sys.argv) > 3 else 5400.0) * 5.0 / Nx
 dt_fast = 300.0 * 5.0 / Nx
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 cpu = "--no-cpu" not in sys.argv
+# polynomial order of the barotropic grid along its extrusion (--extrusion=1: two nodes)
+ext = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--extrusion=")]
+N_ext = ext[0] if ext else None
 O = cm.ocean
 t0 = time.time()
-law3, g3, law2, g2 = split_explicit_setup(True, Nx=Nx, Ny=Nx, Nz=Nz)
+law3, g3, law2, g2 = split_explicit_setup(True, Nx=Nx, Ny=Nx, Nz=Nz, N_extrusion=N_ext)
 print("grids: %.1f s" % (time.time() - t0), file=sys.stderr, flush=True)
 dg3 = cm.dgmodel.DGModel(law3, g3)
 keep = O.install_hydrostatic_boussinesq_hooks(dg3)
@@ -48,8 +51,9 @@ RKC = se.RKC
 nsub = sum(int(np.ceil(((1 - RKC[s]) if s == 4 else (RKC[s + 1] - RKC[s])) * dt_slow / dt_fast))
            for s in range(5))
 out = {"workload": "split-explicit ocean box %dx%dx%d elements, N=4 (%d 3-D elements, %d columns), "
-                   "dt_slow=%g s, dt_fast<=%g s (%d barotropic LSRK54 steps per slow step), Coupled"
-                   % (Nx, Nx, Nz, g3.nreal, g2.nreal, dt_slow, dt_fast, nsub),
+                   "dt_slow=%g s, dt_fast<=%g s (%d barotropic LSRK54 steps per slow step), Coupled; "
+                   "barotropic grid %d nodes per element"
+                   % (Nx, Nx, Nz, g3.nreal, g2.nreal, dt_slow, dt_fast, nsub, g2.Np),
        "ms_per_slow_step": 1e3 * el / steps, "ms_per_slow_step_with_events": 1e3 * el_ev / steps,
        "node_updates_per_s_3d": g3.nreal * g3.Np * 5 * steps / el,
        "state_finite": bool(torch.isfinite(Q3).all().item() and torch.isfinite(Q2).all().item())}

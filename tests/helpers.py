@@ -22,6 +22,23 @@ def pseudo1d_setup(Ne=4, N=4, direction=0, flux_bc=False, rank=0, size=1, dim=3)
     return law, grid, dt
 
 
+def variable_degree_setup(level=1, orders=(4, 2), field="horizontal"):
+    """variable_degree_advection_diffusion.jl:77-150 (dim = 3): polynomialorder = (N_h, N_v); its
+    two equations are uncoupled (per-equation wave speed and diffusion tensor), so each is run
+    as the one-equation Pseudo1D problem along n_hd = (1, 1, 0)/sqrt(2) or n_vd = (0, 0, 1);
+    the operator works in every direction."""
+    Ne = 2 ** (level - 1) * 4
+    n = np.array([1, 1, 0]) / np.sqrt(2) if field == "horizontal" else np.array([0, 0, 1.0])
+    rng = [np.linspace(-1, 1, Ne + 1)] * 3
+    topl = M.StackedBrickTopology(rng, boundary=((1, 2),) * 3, periodicity=(False,) * 3,
+                                  connectivity="full")
+    grid = M.DiscontinuousSpectralElementGrid(topl, (orders[0], orders[0], orders[1]))
+    law = BL.AdvectionDiffusion(3, BL.Pseudo1D(n, 1.0, 1 / 100, -1 / 2, 1 / 10),
+                                (BL.InhomogeneousBC(0), BL.InhomogeneousBC(1)))
+    dt = (1.0 / 4) / (Ne * max(orders) ** 2)
+    return law, grid, dt
+
+
 def rel_linf(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
@@ -247,7 +264,7 @@ def heat_eqn_setup(level=1, direction=0, N=4, rank=0, size=1):
     return law, grid, 0.01 / nsteps, nsteps
 
 
-def split_explicit_setup(coupled=True, Nx=5, Ny=5, Nz=8, N=4):
+def split_explicit_setup(coupled=True, Nx=5, Ny=5, Nz=8, N=4, N_extrusion=None):
     """test/Ocean/SplitExplicit/hydrostatic_spindown.jl:3-140 (SplitExplicitSolver variant):
     SimpleBox 1e6 x 1e6 x 400 m, 3-D HBModel (c_h = 1, alpha_T = kappa = 0, default Coriolis
     parameters but a Fixed box, so f = -0) + 2-D ShallowWaterModel (ConstantViscosity(nu_h),
@@ -262,7 +279,7 @@ def split_explicit_setup(coupled=True, Nx=5, Ny=5, Nz=8, N=4):
     topl = M.StackedBrickTopology([x, y, np.linspace(-H, 0.0, Nz + 1)],
                                   periodicity=(True, True, False), boundary=((0, 0), (0, 0), (1, 2)))
     grid3 = M.DiscontinuousSpectralElementGrid(topl, N)
-    grid2 = O.extruded_barotropic_grid(x, y, N)
+    grid2 = O.extruded_barotropic_grid(x, y, N, N_extrusion=N_extrusion)
     return law3, grid3, law2, grid2
 
 
