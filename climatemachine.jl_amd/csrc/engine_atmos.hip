@@ -20,6 +20,13 @@ template <int NQ>
 static EngineBase *pick(const cmdg_desc *d, std::string &err)
 {
     const bool orient = d->iparam[0] != 0, ref = d->iparam[1] != 0, hyp = d->iparam[4] != 0;
+    bool mms = (d->iparam[5] & 8) != 0;
+    for (int i = 0; i < d->iparam[6] && i < 7; ++i) mms = mms || d->iparam[7 + i] == 2;
+    if (mms && (orient || ref || hyp || d->iparam[14] != 0)) {
+        err = "DryAtmos: MMSSource / InitStateBC are compiled for NoOrientation, NoReferenceState, "
+              "constant viscosity only";
+        return nullptr;
+    }
     if (d->iparam[14] == 1) {  // SmagorinskyLilly (AtmosLES configurations)
         if (orient && ref && !hyp) return make_engine<DryAtmos<true, true, false, true>, NQ>(d);
         err = "DryAtmos: SmagorinskyLilly is compiled with orientation + reference state, no hyperdiffusion";

@@ -118,6 +118,8 @@ struct DryAtmos {
     }
 
     // ---- local Courant numbers: src/Atmos/Model/courant.jl:12-83 ------------------------
+    // the manufactured-solution pieces (source, InitStateBC) exist in the plain variant only
+    static constexpr bool MMS_VARIANT = !ORIENT && !REF && !HYPER && !SMAG;
     static constexpr bool HAS_COURANT = true;
     static constexpr bool HAS_PENALTY = false;  // update_penalty! is the default no-op
     __device__ static void update_penalty(const Params &, double *, const double *, const double *,
@@ -340,7 +342,7 @@ struct DryAtmos {
         S[2] = Sm[1];
         S[3] = Sm[2];
         S[4] = Se;
-        if constexpr (!ORIENT && !REF && !HYPER && !SMAG) {
+        if constexpr (MMS_VARIANT) {
             if (m.src & 8) {  // MMSSource{3} (mms_bc_atmos.jl:65-86)
                 double Sx[5];
                 mms_source(m, t, aux[0], aux[1], aux[2], Sx);
@@ -520,9 +522,13 @@ struct DryAtmos {
                                           double *auxP, const double *n, const double *QM,
                                           const double *, double t, const double *, const double *)
     {
-        if (m.bc[bctag - 1] == 2) {  // InitStateBC (bc_initstate.jl:12-26): the exact solution
-            mms_state(t, auxP[0], auxP[1], auxP[2], QP);
-            return;
+        // InitStateBC (bc_initstate.jl:12-26): the exact solution.  Only the plain variant of
+        // the functor carries it, so the production kernels pay no registers for it
+        if constexpr (MMS_VARIANT) {
+            if (m.bc[bctag - 1] == 2) {
+                mms_state(t, auxP[0], auxP[1], auxP[2], QP);
+                return;
+            }
         }
         if (m.bc[bctag - 1] == 1) {  // Impenetrable(FreeSlip) + Insulating
             const double dn = QM[1] * n[0] + QM[2] * n[1] + QM[3] * n[2];
@@ -544,14 +550,16 @@ struct DryAtmos {
                                                       double t, const double *, const double *,
                                                       const double *)
     {
-        if (m.bc[bctag - 1] != 2) return;
-        mms_state(t, auxP[0], auxP[1], auxP[2], QP);
-        double FPl[15];
+        if constexpr (MMS_VARIANT) {
+            if (m.bc[bctag - 1] != 2) return;
+            mms_state(t, auxP[0], auxP[1], auxP[2], QP);
+            double FPl[15];
 #pragma unroll
-        for (int q = 0; q < 15; ++q) FPl[q] = -0.0;
-        flux_second_order(m, FPl, QP, gfP, hypP, auxP, t);
+            for (int q = 0; q < 15; ++q) FPl[q] = -0.0;
+            flux_second_order(m, FPl, QP, gfP, hypP, auxP, t);
 #pragma unroll
-        for (int q = 0; q < 15; ++q) F[q] += FPl[q];
+            for (int q = 0; q < 15; ++q) F[q] += FPl[q];
+        }
     }
     __device__ static void boundary_state_divergence(const Params &, int, double *, double *,
                                                      const double *, const double *,
