@@ -93,6 +93,36 @@ def test_three_rank_connectivity_tables(key, conn):
         assert np.array_equal(np.unique(t.sendelems), t.exteriorelems)
 
 
+def test_two_rank_stacked_3d_connectivity_tables():
+    """test/Numerics/Mesh/mpi_connect_stacked_3d.jl: 3 x 3 x 3 stacked brick on two ranks,
+    periodic in y, face connectivity -- element order, coordinates, neighbours, faces,
+    boundary tags and the neighbour send / receive ranges."""
+    fx = json.load(open(os.path.join(GOLD, "mesh_connect.json")))["mpi_connect_stacked_3d"]
+    gcoord = np.array(fx["globalelemtocoord"])            # (27, 3, 8)
+    gbndy = np.array(fx["globalelemtobndy"]).T            # (27, 6)
+    gface = np.array(fx["globalelemtoface"]).T
+    for r, exp in enumerate(fx["ranks"]):
+        t = M.StackedBrickTopology((np.arange(1, 5), np.arange(5, 9), np.arange(9, 13)),
+                                   periodicity=(False, True, False),
+                                   boundary=((1, 2), (3, 4), (5, 6)), connectivity="face",
+                                   rank=r, size=2)
+        ge = np.array(exp["globalelems"]) - 1
+        assert t.nreal == exp["nrealelem"] and t.nelem == len(ge)
+        # elemtocoord here is (nelem, nvert, dim); the fixture (dim, nvert) per element
+        assert np.array_equal(np.transpose(t.elemtocoord, (0, 2, 1)), gcoord[ge])
+        assert np.array_equal(t.elemtoelem.T, np.array(exp["elemtoelem"]))
+        assert np.array_equal(t.elemtobndy, gbndy[ge])
+        assert np.array_equal(t.elemtoface[:t.nreal], gface[ge[:t.nreal]])
+        assert (t.elemtoordr == 1).all()
+        assert t.nabrtorank == exp["nabrtorank"]
+        assert [list(x) for x in t.nabrtorecv] == exp["nabrtorecv"]
+        assert [list(x) for x in t.nabrtosend] == exp["nabrtosend"]
+        both = np.sort(np.concatenate([t.exteriorelems, t.interiorelems]))
+        assert np.array_equal(both, np.arange(1, t.nreal + 1))
+        assert np.array_equal(np.unique(t.sendelems), t.exteriorelems)
+        assert len(np.intersect1d(t.exteriorelems, t.interiorelems)) == 0
+
+
 def test_lgl_and_derivative():  # Elements.jl (test): exact N=4 rule, D exact on P_N
     x, w = M.elements.lglpoints(4)
     assert np.allclose(x, [-1, -np.sqrt(3 / 7), 0, np.sqrt(3 / 7), 1], atol=1e-15)
