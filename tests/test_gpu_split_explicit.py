@@ -155,3 +155,22 @@ def test_device_split_explicit_reproduces_reference_tables(cm, oracle, torch, na
         err = np.sqrt(oracle.weighted_norm2_local(g, Q, Qe) / oracle.weighted_norm2_local(g, Qe))
         assert err < 0.005
     _close(dg3, dg2, keep)
+
+
+@pytest.mark.parametrize("N_extrusion", [None, 1])
+def test_shallow_water_alone_reproduces_reference_table(cm, oracle, torch, N_extrusion):
+    """test/Ocean/ShallowWater/test_2D_spindown.jl on the device (five- and two-node extrusion)."""
+    from test_shallow_water_oracle import GOLD as G2, plane_fields, shallow_spindown_setup
+    law, grid, dt, nsteps = shallow_spindown_setup(N_extrusion)
+    dg = cm.dgmodel.DGModel(law, grid,
+                            numerical_flux_first_order=cm.balancelaws.CentralNumericalFluxFirstOrder)
+    Q = dg.init_ode_state(0.0)
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+    solver.dostep(Q, nsteps=nsteps)
+    dg.synchronize()
+    Qn = Q.cpu().numpy()
+    check_split_explicit_table(G2["explicit"], G2["parr"], plane_fields(Qn, grid), slack=2.0)
+    Qe = law.init_state_prognostic(grid, dg.state_auxiliary.cpu().numpy(), 86400.0)
+    err = np.sqrt(oracle.weighted_norm2_local(grid, Qn, Qe) / oracle.weighted_norm2_local(grid, Qe))
+    assert err < 0.005
+    dg.close()
