@@ -490,7 +490,7 @@ int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, doubl
 int EngineBase::courant(int mode, int kind, const double *Q, double dt, double t, int dir,
                         double *out)
 {
-    if (dir < 0 || dir > 2 || kind < 0 || kind > 2) return fail(CMDG_ERR_INVALID, "courant: bad argument");
+    if (dir < 0 || dir > 2 || kind < 0 || kind > 3) return fail(CMDG_ERR_INVALID, "courant: bad argument");
     if (g.nvgeo < 15) return fail(CMDG_ERR_INVALID, "courant: vgeo lacks the coordinate columns");
     if (nreal == 0) {  // typemin / typemax (SpaceDiscretization.jl:359-361, Grids.jl:481-483)
         *out = mode == 0 ? INFINITY : -INFINITY;

@@ -33,7 +33,7 @@ struct HydroBoussinesq {
     enum { GDIVH = 0, GNU = 1, GKAPPA = 7 };
     static constexpr int NS = 4, NAUX = 8, NGRAD = 5, NGF = 10, NGL = 0, NHYP = 0;
     static constexpr bool HAS_UPDATE_AUX = false, FUSE_UPDATE_AUX = false, HAS_SOURCE = true;
-    static constexpr bool HAS_COURANT = false, HAS_PENALTY = true;
+    static constexpr bool HAS_COURANT = true, HAS_PENALTY = true;
     static constexpr int NUPD = 0, NDER = 0;
     __host__ __device__ static constexpr int upd_aux(int) { return 0; }
     __host__ __device__ static constexpr int hv_indexmap(int) { return 0; }
@@ -249,10 +249,30 @@ struct HydroBoussinesq {
     }
     __device__ static void update_aux(const Params &, const double *, double *, double) {}
     __host__ __device__ static bool update_aux_active(const Params &) { return false; }
-    __device__ static double courant(const Params &, int, const double *, const double *,
-                                     const double *, double, double, double, int)
+    // local Courant numbers of src/Ocean/HydrostaticBoussinesq/Courant.jl:13-111:
+    // kind 0 advective (|w|, |u| or |(u, v, w)| by direction), 1 nondiffusive (gravity waves,
+    // c_h), 2 diffusive (kappa; the factor 1000 on kappa_z stands for convective adjustment),
+    // 3 viscous (nu)
+    __device__ static double courant(const Params &m, int kind, const double *Q, const double *aux,
+                                     const double *, double dx, double dt, double, int direction)
     {
-        return 0.0;
+        if (kind == 0) {
+            double ub;
+            if (direction == DIR_VERTICAL)
+                ub = fabs(aux[AW]);
+            else if (direction == DIR_HORIZONTAL)
+                ub = sqrt(Q[U] * Q[U] + Q[V] * Q[V]);
+            else
+                ub = sqrt(Q[U] * Q[U] + Q[V] * Q[V] + aux[AW] * aux[AW]);
+            return dt * ub / dx;
+        }
+        if (kind == 1) return dt * m.ch / dx;
+        const double h = kind == 3 ? m.nuh : m.kh;
+        const double z = kind == 3 ? m.nuz : 1000 * m.kz;
+        const double nb = direction == DIR_VERTICAL     ? z
+                          : direction == DIR_HORIZONTAL ? sqrt(2.0) * h
+                                                        : sqrt(2 * (h * h) + z * z);
+        return dt * nb / (dx * dx);
     }
 };
 

@@ -25,6 +25,9 @@ __all__ = ["HydrostaticBoussinesqModel", "ShallowWaterModel", "extruded_barotrop
            "IMPENETRABLE_KINEMATIC_STRESS", "PENETRABLE_KINEMATIC_STRESS", "INSULATING",
            "TEMPERATURE_FLUX", "install_hydrostatic_boussinesq_hooks"]
 
+# local Courant numbers of the ocean model (kind argument of cmdg_courant)
+OCEAN_ADVECTIVE_COURANT, OCEAN_NONDIFFUSIVE_COURANT = 0, 1
+OCEAN_DIFFUSIVE_COURANT, OCEAN_VISCOUS_COURANT = 2, 3
 IMPENETRABLE_NOSLIP, IMPENETRABLE_FREESLIP, PENETRABLE_FREESLIP = 1, 2, 3
 IMPENETRABLE_KINEMATIC_STRESS, PENETRABLE_KINEMATIC_STRESS = 4, 5
 INSULATING, TEMPERATURE_FLUX = 0, 1
@@ -131,6 +134,18 @@ class HydrostaticBoussinesqModel:
         dp[11:16] = [getattr(pr, "tau_o", 0.0), self.rho_o, pr.Ly, getattr(pr, "lambda_r", 0.0),
                      getattr(pr, "theta_E", 0.0)]
         return ip, dp
+
+    def calculate_dt(self, courant, Courant_number, t=0.0):
+        """``calculate_dt(dg, model::HBModel, Q, Courant_number, t, ::EveryDirection)``
+        (src/Ocean/HydrostaticBoussinesq/Courant.jl:113-159): the smallest of the advective
+        (vertical), gravity-wave (horizontal), viscous and diffusive (vertical) limits.
+        ``courant(kind, direction)`` evaluates ``courant(local_courant, dg, m, Q, 1, t,
+        direction)`` -- ``dg.courant`` of the device operator or the oracle's."""
+        V, H = 2, 1
+        cfls = [courant(OCEAN_ADVECTIVE_COURANT, V), courant(OCEAN_NONDIFFUSIVE_COURANT, H),
+                courant(OCEAN_VISCOUS_COURANT, V), courant(OCEAN_DIFFUSIVE_COURANT, V)]
+        with np.errstate(divide="ignore"):
+            return min(Courant_number / np.float64(c) for c in cfls)
 
     def init_state_auxiliary(self, grid):
         """``ocean_init_aux!`` (simple_box_problem.jl:12-22): y, everything else -0."""

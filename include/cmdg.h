@@ -168,8 +168,12 @@ int cmdg_distance2_local(cmdg_handle h, const double *A, const double *B, int32_
                          double *out_host);
 
 /* ---- Courant numbers and time-step selection ------------------------------------------ */
-/* local_courant functions of src/Atmos/Model/courant.jl:29-83 */
-enum { CMDG_ADVECTIVE_COURANT = 0, CMDG_NONDIFFUSIVE_COURANT = 1, CMDG_DIFFUSIVE_COURANT = 2 };
+/* local_courant functions of src/Atmos/Model/courant.jl:29-83 and, for the ocean model,
+ * src/Ocean/HydrostaticBoussinesq/Courant.jl:13-111 (which adds viscous_courant) */
+enum {
+    CMDG_ADVECTIVE_COURANT = 0, CMDG_NONDIFFUSIVE_COURANT = 1, CMDG_DIFFUSIVE_COURANT = 2,
+    CMDG_VISCOUS_COURANT = 3
+};
 /* courant(local_courant, dg, m, Q, dt, simtime, direction) (SpaceDiscretization.jl:307-365):
  * maximum over this rank's real nodes of the law's local Courant number, with dx the
  * minimum neighbour distance of the node in `direction`; -inf when the rank owns no element.

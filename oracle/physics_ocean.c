@@ -224,6 +224,29 @@ static void oc_bhigher(const void *p, int b, double *QP, double *aP, double *lP,
     (void)p; (void)b; (void)QP; (void)aP; (void)lP; (void)n; (void)QM; (void)aM; (void)lM; (void)t;
 }
 
+/* src/Ocean/HydrostaticBoussinesq/Courant.jl:13-111: kind 0 advective, 1 nondiffusive (gravity
+   waves), 2 diffusive (1000 kappa_z for convective adjustment), 3 viscous */
+static double oc_courant(const void *p_, int kind, const double *Q, const double *aux,
+                         const double *gf, double dx, double dt, double t, int direction)
+{
+    const ocean_t *m = (const ocean_t *)p_;
+    (void)gf; (void)t;
+    if (kind == 0) {
+        double ub;
+        if (direction == ORC_VERTICAL) ub = fabs(aux[AW]);
+        else if (direction == ORC_HORIZONTAL) ub = sqrt(Q[U] * Q[U] + Q[V] * Q[V]);
+        else ub = sqrt(Q[U] * Q[U] + Q[V] * Q[V] + aux[AW] * aux[AW]);
+        return dt * ub / dx;
+    }
+    if (kind == 1) return dt * m->ch / dx;
+    const double h = kind == 3 ? m->nuh : m->kh;
+    const double z = kind == 3 ? m->nuz : 1000 * m->kz;
+    const double nb = direction == ORC_VERTICAL ? z
+                    : direction == ORC_HORIZONTAL ? sqrt(2.0) * h
+                    : sqrt(2 * (h * h) + z * z);
+    return dt * nb / (dx * dx);
+}
+
 orc_physics *orc_ocean_new(const int *ip, const double *dp, int nf_first)
 {
     orc_physics *ph = (orc_physics *)calloc(1, sizeof(orc_physics));
@@ -251,5 +274,6 @@ orc_physics *orc_ocean_new(const int *ip, const double *dp, int nf_first)
     ph->boundary_state_divergence = oc_bdiv;
     ph->boundary_state_higher_order = oc_bhigher;
     ph->update_penalty = oc_penalty;
+    ph->courant = oc_courant;
     return ph;
 }

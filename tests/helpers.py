@@ -162,13 +162,13 @@ def ocean_spindown_setup(Nx=5, Ny=5, Nz=8, N=4, rank=0, size=1):
     return law, grid
 
 
-def ocean_gyre_setup(Nx=5, Ny=5, Nz=5, N=4, rank=0, size=1):
+def ocean_gyre_setup(Nx=5, Ny=5, Nz=5, N=4, rank=0, size=1, L=1e6):
     """test/Ocean/HydrostaticBoussinesq/test_ocean_gyre_short.jl with
     experiments/OceanBoxGCM/simple_box.jl: OceanGyre 1e6 x 1e6 x 1000 m, 5^3 elements, N = 4,
     c_h = sqrt(g H), every other parameter at its default, non-periodic box with boundary tags
     ((1,1),(1,1),(2,3)) (OceanBoxGCMConfiguration defaults); dt = 120 s, LSRK144, one hour."""
     O = cm.ocean
-    Lx, Ly, H = 1e6, 1e6, 1000.0
+    Lx, Ly, H = L, L, 1000.0       # test_ocean_gyre_long.jl: 4e6 x 4e6 x 1000 m on 20^3 elements
     problem = O.OceanGyre(Lx, Ly, H)
     law = O.HydrostaticBoussinesqModel(problem, c_h=np.sqrt(9.81 * H))
     rng = [np.linspace(0.0, Lx, Nx + 1), np.linspace(0.0, Ly, Ny + 1), np.linspace(-H, 0.0, Nz + 1)]

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from helpers import ocean_gyre_setup, ocean_spindown_setup, ocean_windstress_setup, rel_linf
-from test_ocean_oracle import GOLD, WIND, check_against_refvals, check_gyre_refvals
+from test_ocean_oracle import GOLD, GYRE, WIND, check_against_refvals, check_gyre_refvals
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-12
@@ -176,6 +176,56 @@ def test_windstress_short_reference_regression_on_the_gpu(cm, torch):
     dg.synchronize()
     table = [r for r in WIND["explicit_cpu"] if r[1] != "θ"]
     assert check_gyre_refvals(Q.cpu().numpy(), dg.state_auxiliary.cpu().numpy(), table=table, rtol=2e-11) == 28
+    dg.set_rhs_hooks()
+    for f in keep:
+        f.close()
+    dg.close()
+
+
+def test_ocean_courant_numbers_and_dt_match_oracle(cm, oracle, torch):
+    """src/Ocean/HydrostaticBoussinesq/Courant.jl: the four local Courant numbers in the
+    directions calculate_dt uses them, and the resulting time step."""
+    O, F = cm.ocean, cm.mesh.filters
+    law, grid = ocean_gyre_setup()
+    dg = cm.dgmodel.DGModel(law, grid)
+    odg = oracle.OracleDGModel(law, grid)
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    rng = np.random.default_rng(4)
+    Q0[:, 0:2] = 0.05 * rng.standard_normal(Q0[:, 0:2].shape)
+    w = 1e-3 * rng.standard_normal(Q0[:, 0].shape)
+    odg.state_auxiliary[:, 1] = w
+    dg.state_auxiliary[:, 1] = _gpu(torch, w)
+    Qg = _gpu(torch, Q0)
+    for kind in (0, 1, 2, 3):
+        for d in (0, 1, 2):
+            o = oracle.courant(kind, odg, Q0, 7.0, 0.0, d)
+            g = dg.courant(kind, Qg, 7.0, 0.0, d)
+            assert abs(g - o) <= 1e-13 * abs(o), (kind, d, g, o)
+    dt_o = law.calculate_dt(lambda k, d: oracle.courant(k, odg, Q0, 1.0, 0.0, d), 0.4)
+    dt_g = law.calculate_dt(lambda k, d: dg.courant(k, Qg, 1.0, 0.0, d), 0.4)
+    assert abs(dt_g - dt_o) <= 1e-13 * dt_o
+    dg.close()
+
+
+def test_ocean_gyre_long_reference_regression_on_the_gpu(cm, torch):
+    """test_ocean_gyre_long.jl: 20^3 elements, 4e6 x 4e6 x 1000 m, one simulated day of explicit
+    LSRK144 steps with dt = calculate_dt(Courant number 0.4) adjusted to divide the day (620
+    steps of 139.35 s), against the `long` StateCheck rows."""
+    O = cm.ocean
+    law, grid = ocean_gyre_setup(Nx=20, Ny=20, Nz=20, L=4e6)
+    dg = cm.dgmodel.DGModel(law, grid)
+    keep = O.install_hydrostatic_boussinesq_hooks(dg)
+    Q = dg.init_ode_state(0.0)
+    dt = law.calculate_dt(lambda k, d: dg.courant(k, Q, 1.0, 0.0, d), 0.4)
+    nsteps = int(np.ceil(86400.0 / dt))            # solver_configs.jl:247-249
+    assert nsteps == 620
+    dt = 86400.0 / nsteps
+    solver = cm.odesolvers.LSRK144NiegemannDiehlBusch(dg, Q, dt=dt)
+    solver.dostep(Q, nsteps=nsteps)
+    dg.synchronize()
+    n = check_gyre_refvals(Q.cpu().numpy(), dg.state_auxiliary.cpu().numpy(), rtol=1e-10,
+                           table=GYRE["long"])
+    assert n == 32
     dg.set_rhs_hooks()
     for f in keep:
         f.close()
