@@ -297,6 +297,14 @@ def main():
                                    "%d steps (%.3f ms/step with events)" % (
                                        args.steps, 1e3 * el_events / args.steps)},
         }
+        # flops of the (N+1)-point derivative contractions alone (2 (N+1) per
+        # node, differentiated scalar and direction): gradient arguments, the two hyperdiffusion
+        # passes, the tendency.  Secondary figure: the path is HBM bound (< 1 flop/B), the
+        # contraction runs on fp64 VALU out of LDS, not on MFMA.
+        cf = 6 * (grid.N[0] + 1) * (law.ngrad + 2 * law.ngradlap + law.ns)
+        out["contraction"] = {"flops_per_node_update": cf,
+                              "achieved_TFLOPs": cf * (dofs / law.ns) / el / 1e12,
+                              "unit": "fp64 VALU (no MFMA)"}
         if "FILTER" in kern:
             # Q read + written (5 fields each) and the two reference-state columns
             fb = 8 * (2 * law.ns + 2) * grid.Np * grid.nreal
