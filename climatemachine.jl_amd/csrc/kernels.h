@@ -185,9 +185,8 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
                   NHYP = P::NHYP, NHG = 3 * P::NGL, NFA = P::NFAUX,
                   NSURF = SurfDims<NQ, NQV>::NSURF, NGFS = USE_GF ? NGF : 0,
                   NMF = NS + NFA + NGFS + NHYP;
-    __shared__ double sD[NQ * NQ];
-    __shared__ double sDv_[NQV == NQ ? 1 : NQV * NQV];
-    const double *const sDv = NQV == NQ ? sD : sDv_;  // vertical derivative matrix
+    __shared__ double sD[NQ * NQ + (NQV == NQ ? 0 : NQV * NQV)];
+    const double *const sDv = sD + (NQV == NQ ? 0 : NQ * NQ);  // vertical derivative matrix
     __shared__ double sF[3 * NS * Np];  // contravariant flux [d][s][ijk]; later the accumulator
     __shared__ double sM[NMF * NSURF];  // minus-side state of the surface nodes [field][sidx]
     double *const sT = sF;              // tendency accumulator [s][ijk] (aliases sF after phase 2)
@@ -195,7 +194,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
     if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
     if constexpr (NQV != NQ) {
-        if (tid < NQV * NQV) sDv_[tid] = a.g.Dv[tid];
+        if (tid < NQV * NQV) sD[NQ * NQ + tid] = a.g.Dv[tid];
     }
     const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
     // USE_GF: does flux_second_order depend on the gradient-flux state at all?  With zero
@@ -204,10 +203,13 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
     constexpr bool use_gf = NGF > 0 && USE_GF;
     int64_t f_idM = 1, f_idP = 1;
     int f_bctag = 0;
-    int f_f = 0, f_n = 0;
-    KD::face_task(tid, f_f, f_n);
-    const bool face_on = tid < KD::NFT && (f_f < 4 ? hz : vt);
-    if (face_on) face_index<NQ, NQV>(a.g, e, f_f, f_n, f_idM, f_idP, f_bctag);
+    bool face_on;
+    {
+        int f_f = 0, f_n = 0;
+        KD::face_task(tid, f_f, f_n);
+        face_on = tid < KD::NFT && (f_f < 4 ? hz : vt);
+        if (face_on) face_index<NQ, NQV>(a.g, e, f_f, f_n, f_idM, f_idP, f_bctag);
+    }
     Vec<NS> S;
     double MI = 0;
     if (tid < Np) {
@@ -321,7 +323,8 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
 #else
     if (tid < KD::NFT) {
 #endif
-        const int f = f_f, n = f_n;
+        int f, n;  // recomputed: cheaper than two registers live across the volume phases
+        KD::face_task(tid, f, n);
         if (face_on) {
             const int facedir = f < 4 ? DIR_HORIZONTAL : DIR_VERTICAL;
             FacePt fp;
@@ -446,16 +449,15 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? C
     using KD = KDims<NQ, NQV>;
     constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGRAD = P::NGRAD,
                   NGF = P::NGF, NGL = P::NGL, NHG = 3 * NGL, NACC = NGF + NHG;
-    __shared__ double sD[NQ * NQ];
-    __shared__ double sDv_[NQV == NQ ? 1 : NQV * NQV];
-    const double *const sDv = NQV == NQ ? sD : sDv_;  // vertical derivative matrix
+    __shared__ double sD[NQ * NQ + (NQV == NQ ? 0 : NQV * NQV)];
+    const double *const sDv = sD + (NQV == NQ ? 0 : NQ * NQ);  // vertical derivative matrix
     __shared__ double sG[(NGRAD > 0 ? NGRAD : 1) * Np];
     __shared__ double sA[(NACC > 0 ? NACC : 1) * Np];  // [gf..., hypgrad...][ijk]
     const int tid = threadIdx.x;
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
     if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
     if constexpr (NQV != NQ) {
-        if (tid < NQV * NQV) sDv_[tid] = a.g.Dv[tid];
+        if (tid < NQV * NQV) sD[NQ * NQ + tid] = a.g.Dv[tid];
     }
     const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
     Vec<NS> lQ;
@@ -632,9 +634,8 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT)) k_divgrad(const PassArgs
     using KD = KDims<NQ, NQV>;
     constexpr int Np = KD::Np, NAUX = P::NAUX, NGL = P::NGL, NHG = 3 * NGL,
                   NHYP = P::NHYP, NG = NGL > 0 ? NGL : 1;
-    __shared__ double sD[NQ * NQ];
-    __shared__ double sDv_[NQV == NQ ? 1 : NQV * NQV];
-    const double *const sDv = NQV == NQ ? sD : sDv_;  // vertical derivative matrix
+    __shared__ double sD[NQ * NQ + (NQV == NQ ? 0 : NQV * NQV)];
+    const double *const sDv = sD + (NQV == NQ ? 0 : NQ * NQ);  // vertical derivative matrix
     __shared__ double sC[3 * NG * Np];  // M * (xi_d . grad) [d][s][ijk]
     __shared__ double sA[NG * Np];
     constexpr int NSURF = SurfDims<NQ, NQV>::NSURF;
@@ -643,7 +644,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT)) k_divgrad(const PassArgs
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
     if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
     if constexpr (NQV != NQ) {
-        if (tid < NQV * NQV) sDv_[tid] = a.g.Dv[tid];
+        if (tid < NQV * NQV) sD[NQ * NQ + tid] = a.g.Dv[tid];
     }
     const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
     double MI = 0;
@@ -752,16 +753,15 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_LAP_MINW) k_gradlap
     constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGL = P::NGL,
                   NHG = 3 * NGL, NHYP = P::NHYP, NG = NGL > 0 ? NGL : 1,
                   NH = NHYP > 0 ? NHYP : 1;
-    __shared__ double sD[NQ * NQ];
-    __shared__ double sDv_[NQV == NQ ? 1 : NQV * NQV];
-    const double *const sDv = NQV == NQ ? sD : sDv_;  // vertical derivative matrix
+    __shared__ double sD[NQ * NQ + (NQV == NQ ? 0 : NQV * NQV)];
+    const double *const sDv = sD + (NQV == NQ ? 0 : NQ * NQ);  // vertical derivative matrix
     __shared__ double sL[NG * Np];
     __shared__ double sA[NH * Np];
     const int tid = threadIdx.x;
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
     if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
     if constexpr (NQV != NQ) {
-        if (tid < NQV * NQV) sDv_[tid] = a.g.Dv[tid];
+        if (tid < NQV * NQV) sD[NQ * NQ + tid] = a.g.Dv[tid];
     }
     const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
     if (tid < Np) {
