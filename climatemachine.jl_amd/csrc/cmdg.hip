@@ -351,6 +351,9 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
         if (comm) {
             TRY(halo_end(SLOT_Q, c.Qin, ns));
             launch_update_aux(c, nreal, nelem);
+            // update_auxiliary_state!(ghostelems): the flow deviation of the ghost stacks
+            if (has_hooks && hooks.has_flow_deviation)
+                TRY(flow_deviation(c.Qin, nreal / hooks.nvertelem, nghost / hooks.nvertelem));
         }
         launch_gradients(c, d_exterior, nexterior);
         if (gradient_filter && ngf > 0) TRY(filter_apply(gradient_filter, gf, ngf));  // (:185-193)
@@ -634,23 +637,33 @@ int EngineBase::run_pre_hooks(const RhsCtx &c)
     for (int i = 0; i < hooks.npre; ++i)
         if (int r = filter_apply(reinterpret_cast<const FilterObj *>(hooks.pre_filter[i]), c.Qin, ns))
             return r;
-    if (hooks.has_flow_deviation) {
-        // compute_flow_deviation!(dg, ::HBModel, ::Coupled, Q, t)
-        // (HydrostaticBoussinesqCoupling.jl:43-85): u_d = u - (1/H) int u dz
-        if (int r = integrate_velocity(c.Qin, ns, hooks.flow_u_col, hooks.nvertelem)) return r;
-        const int64_t n = (int64_t)nreal * Np;
-        hipLaunchKernelGGL(k_column_minus_top_over_H, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)),
-                           dim3(256), 0, s_comp, aux, naux, hooks.flow_ud_col, (const double *)c.Qin, ns,
-                           hooks.flow_u_col, (const double *)d_flowint, hooks.flow_H, NQ * NQ, NQ,
-                           hooks.nvertelem, (int64_t)(nreal / hooks.nvertelem));
-    }
+    if (hooks.has_flow_deviation)
+        if (int r = flow_deviation(c.Qin, 0, nreal / hooks.nvertelem)) return r;
+    return CMDG_OK;
+}
+
+// compute_flow_deviation!(dg, ::HBModel, ::Coupled, Q, t)
+// (HydrostaticBoussinesqCoupling.jl:43-85): u_d = u - (1/H) int u dz on the stacks
+// [h0, h0 + nh).  For ghost stacks (after the exchange of Q) the integral runs over the received
+// face pencils, which is all the neighbours read.
+int EngineBase::flow_deviation(double *Q, int64_t h0, int64_t nh)
+{
+    if (nh <= 0) return CMDG_OK;
+    if (int r = integrate_velocity(Q, ns, hooks.flow_u_col, hooks.nvertelem, h0, nh)) return r;
+    const int64_t n = nh * hooks.nvertelem * Np;
+    hipLaunchKernelGGL(k_column_minus_top_over_H, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)),
+                       dim3(256), 0, s_comp, aux, naux, hooks.flow_ud_col, (const double *)Q, ns,
+                       hooks.flow_u_col, (const double *)d_flowint, hooks.flow_H, NQ * NQ, NQ,
+                       hooks.nvertelem, h0, nh);
     return CMDG_OK;
 }
 
 // update_auxiliary_state!(integral_model, ...) of VerticalIntegralModel.jl:60-81: the upward
 // column integral of X[:, col..col+1, :] into the scratch d_flowint (Np, 2, nelem)
-int EngineBase::integrate_velocity(const double *X, int nstate, int col, int nvert)
+int EngineBase::integrate_velocity(const double *X, int nstate, int col, int nvert, int64_t h0,
+                                   int64_t nh)
 {
+    if (nh < 0) nh = nreal / nvert;
     if (!d_flowint) HIPCHK(hipMalloc(&d_flowint, sizeof(double) * 2 * Np * nelem));
     cmdg_stack_integral_desc d{};
     d.nout = 2;
@@ -660,7 +673,7 @@ int EngineBase::integrate_velocity(const double *X, int nstate, int col, int nve
         d.scale[c] = 1.0;
         d.dst_col[c] = c;
     }
-    return stack_integral(false, X, nstate, d_flowint, 2, nvert, nullptr, &d, 0, nreal / nvert);
+    return stack_integral(false, X, nstate, d_flowint, 2, nvert, nullptr, &d, h0, nh);
 }
 
 int EngineBase::run_gradient_hooks(const RhsCtx &c, int64_t e0, int64_t e1)

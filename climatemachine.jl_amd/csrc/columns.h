@@ -147,14 +147,14 @@ static __global__ void k_surface_to_column(double *__restrict__ aux, int naux, i
 static __global__ void k_column_minus_top_over_H(double *__restrict__ dst, int ndst, int dcol,
                                                  const double *src, int nsrc, int scol,
                                                  const double *__restrict__ ia, double H, int Nij,
-                                                 int Nqk, int nvert, int64_t nhorz)
+                                                 int Nqk, int nvert, int64_t h0, int64_t nhorz)
 {
     const int Np = Nij * Nqk;
     const int64_t n = nhorz * nvert * Np;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int ijk = (int)(i % Np);
-        const int64_t e = i / Np;
+        const int64_t e = h0 * nvert + i / Np;  // stacks [h0, h0 + nhorz)
         const int64_t et = (nvert - 1) + (e / nvert) * nvert;
         const int top = ijk % Nij + Nij * (Nqk - 1);
 #pragma unroll

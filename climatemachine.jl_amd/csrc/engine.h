@@ -129,7 +129,9 @@ struct EngineBase {
     cmdg_rhs_hooks hooks{};
     int set_hooks(const cmdg_rhs_hooks *hk);
     int run_pre_hooks(const RhsCtx &c);
-    int integrate_velocity(const double *X, int nstate, int col, int nvert);
+    int integrate_velocity(const double *X, int nstate, int col, int nvert, int64_t h0 = 0,
+                           int64_t nh = -1);
+    int flow_deviation(double *Q, int64_t h0, int64_t nh);
     double *d_flowint = nullptr;  // (Np, 2, nelem) column integral of the horizontal velocity
     int run_gradient_hooks(const RhsCtx &c, int64_t e0, int64_t e1);
     double *d_Imat = nullptr;

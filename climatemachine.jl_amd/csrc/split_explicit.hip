@@ -5,6 +5,7 @@
 // Everything is enqueued on the slow engine's compute stream except the fast model's own
 // sub-steps; the two streams are ordered with events, the host never waits.
 #include <cmath>
+#include <vector>
 
 #include "columns.h"
 #include "engine.h"
@@ -36,12 +37,6 @@ int check(cmdg_handle slow, cmdg_handle fast, const cmdg_ocean_coupling_desc *d)
 {
     if (!slow || !fast || !d) return CMDG_ERR_INVALID;
     EngineBase *s = slow->eng, *f = fast->eng;
-    // the flow deviation u_d of ghost columns would have to be integrated from the received
-    // face pencils (as update_auxiliary_state! on ghost elements does); not built yet
-    if (s->communicate() || f->communicate())
-        return s->fail(CMDG_ERR_UNSUPPORTED,
-                       "ocean coupling: partitioned (multi-rank) grids are not supported; run the "
-                       "split-explicit ocean on one rank per column set without ghost elements");
     if (!s->stacked || d->nvertelem < 1 || s->nreal % d->nvertelem)
         return s->fail(CMDG_ERR_INVALID, "ocean coupling: slow grid is not stacked by nvertelem");
     if (f->nreal != s->nreal / d->nvertelem)
@@ -83,7 +78,8 @@ int slow_to_fast(EngineBase *s, EngineBase *f, const cmdg_ocean_coupling_desc *d
                        f->naux, d->fast_GU_col, (const double *)s->d_flowint, Nij, s->NQ, nv, Nqk2, nh);
     hipLaunchKernelGGL(k_column_minus_top_over_H, dim3(nblocks((int64_t)s->nreal * s->Np)), dim3(256),
                        0, s->s_comp, s->aux, s->naux, d->slow_dGu_col, (const double *)s->aux, s->naux,
-                       d->slow_dGu_col, (const double *)s->d_flowint, d->H, Nij, s->NQ, nv, nh);
+                       d->slow_dGu_col, (const double *)s->d_flowint, d->H, Nij, s->NQ, nv,
+                       (int64_t)0, nh);
     return order(s, s->s_comp, f->s_comp);
 }
 
@@ -190,54 +186,93 @@ int cmdg_ssprk_step(cmdg_handle h, double *Q, double *Rstage, double *Qstage, do
     return set_err2(h, launch_status(e));
 }
 
-int cmdg_split_explicit_step(cmdg_handle slow, cmdg_handle fast, const cmdg_ocean_coupling_desc *d,
-                             int32_t coupled, double *Q3, double *dQ3, double *dQ2fast, double *Q2,
-                             double *dQ2, double t, double dt, double dt_fast, int32_t nstages,
-                             const double *rka, const double *rkb, const double *rkc)
+// dostep!(Qslow, split::SplitExplicitSolver, param, time) for n (slow, fast) pairs in lock step:
+// one pair per rank.  With the RCCL transport a process drives its own pair (n = 1); handles
+// connected by cmdg_comm_connect_local are driven together by one host thread.
+static int group_split_explicit_step(int n, cmdg_handle *slow, cmdg_handle *fast,
+                                     const cmdg_ocean_coupling_desc *d, int coupled, double **Q3,
+                                     double **dQ3, double **dQ2fast, double **Q2, double **dQ2,
+                                     double t, double dt, double dt_fast, int nstages,
+                                     const double *rka, const double *rkb, const double *rkc)
 {
-    if (int r = check(slow, fast, d)) return set_err2(slow, r);
-    if (!Q3 || !dQ3 || !dQ2fast || !Q2 || !dQ2 || !rka || !rkb || !rkc || nstages < 1)
-        return CMDG_ERR_INVALID;
-    EngineBase *s = slow->eng, *f = fast->eng;
-#define TRYS(x)                                  \
-    do {                                         \
-        if (int r_ = (x)) return set_err2(slow, r_); \
-    } while (0)
-#define TRYF(x)                                                 \
-    do {                                                        \
-        if (int r_ = (x)) {                                     \
-            s->err = f->err;                                    \
-            return set_err2(slow, r_);                          \
-        }                                                       \
-    } while (0)
+    std::vector<EngineBase *> S(n), F(n);
+    for (int i = 0; i < n; ++i) {
+        if (int r = check(slow[i], fast[i], d)) return set_err2(slow[i], r);
+        if (!Q3[i] || !dQ3[i] || !dQ2fast[i] || !Q2[i] || !dQ2[i]) return CMDG_ERR_INVALID;
+        S[i] = slow[i]->eng;
+        F[i] = fast[i]->eng;
+    }
+    auto bail = [&](std::vector<EngineBase *> &E, int r) {
+        for (int i = 0; i < n; ++i)
+            if (!E[i]->err.empty()) {
+                S[0]->err = E[i]->err;
+                break;
+            }
+        return set_err2(slow[0], r);
+    };
+    std::vector<RhsCtx> c(n);
     for (int st = 0; st < nstages; ++st) {
         const double ts = t + rkc[st] * dt;
-        if (coupled) initialize_states(s, d);
-        RhsCtx c;
-        c.Qin = Q3;
-        c.t = ts;
-        c.alpha = 1.0;
-        // slow.rhs!(dQ2fast, Qslow, param, slow_stage_time, increment = false)
-        c.tendency = dQ2fast;
-        c.beta = 0.0;
-        TRYS(s->rhs_async(c));
-        if (coupled) TRYS(slow_to_fast(s, f, d, dQ2fast));
-        // slow.rhs!(dQslow, Qslow, param, slow_stage_time, increment = true)
-        c.tendency = dQ3;
-        c.beta = 1.0;
-        TRYS(s->rhs_async(c));
+        for (int i = 0; i < n; ++i) {
+            if (coupled) initialize_states(S[i], d);
+            c[i] = RhsCtx();
+            c[i].Qin = Q3[i];
+            c[i].t = ts;
+            c[i].alpha = 1.0;
+            c[i].tendency = dQ2fast[i];  // slow.rhs!(dQ2fast, Qslow, ...; increment = false)
+            c[i].beta = 0.0;
+        }
+        if (int r = group_rhs(S, c)) return bail(S, r);
+        for (int i = 0; i < n; ++i) {
+            if (coupled)
+                if (int r = slow_to_fast(S[i], F[i], d, dQ2fast[i])) return bail(S, r);
+            c[i].tendency = dQ3[i];  // slow.rhs!(dQslow, Qslow, ...; increment = true)
+            c[i].beta = 1.0;
+        }
+        if (int r = group_rhs(S, c)) return bail(S, r);
         // fractional time for the fast sub-steps of this stage
         const double gamma = st == nstages - 1 ? 1 - rkc[st] : rkc[st + 1] - rkc[st];
         const int nsub = dt_fast > 0 ? (int)std::ceil(gamma * dt / dt_fast) : 1;
         const double fdt = gamma * dt / nsub;
         for (int sub = 0; sub < nsub; ++sub)
-            TRYF(f->lsrk_step(Q2, dQ2, ts + sub * fdt, fdt, nstages, rka, rkb, rkc));
-        lsrk_update(s, dQ3, Q3, rka[(st + 1) % nstages], rkb[st] * dt);
-        if (coupled) TRYS(fast_to_slow(s, f, d, Q3, Q2));
+            if (int r = group_lsrk_step(F, Q2, dQ2, ts + sub * fdt, fdt, nstages, rka, rkb, rkc))
+                return bail(F, r);
+        for (int i = 0; i < n; ++i) {
+            lsrk_update(S[i], dQ3[i], Q3[i], rka[(st + 1) % nstages], rkb[st] * dt);
+            if (coupled)
+                if (int r = fast_to_slow(S[i], F[i], d, Q3[i], Q2[i])) return bail(S, r);
+        }
     }
-#undef TRYS
-#undef TRYF
-    return set_err2(slow, launch_status(s));
+    return set_err2(slow[0], launch_status(S[0]));
+}
+
+int cmdg_split_explicit_step(cmdg_handle slow, cmdg_handle fast, const cmdg_ocean_coupling_desc *d,
+                             int32_t coupled, double *Q3, double *dQ3, double *dQ2fast, double *Q2,
+                             double *dQ2, double t, double dt, double dt_fast, int32_t nstages,
+                             const double *rka, const double *rkb, const double *rkc)
+{
+    if (!slow || !fast || !d || !rka || !rkb || !rkc || nstages < 1) return CMDG_ERR_INVALID;
+    if (slow->eng->transport == TRANSPORT_LOCAL && slow->eng->communicate())
+        return set_err2(slow, slow->eng->fail(CMDG_ERR_INVALID,
+                                              "handles connected locally must be driven by "
+                                              "cmdg_group_split_explicit_step"));
+    return group_split_explicit_step(1, &slow, &fast, d, coupled, &Q3, &dQ3, &dQ2fast, &Q2, &dQ2, t,
+                                     dt, dt_fast, nstages, rka, rkb, rkc);
+}
+
+int cmdg_group_split_explicit_step(cmdg_handle *slow, cmdg_handle *fast, int32_t n,
+                                   const cmdg_ocean_coupling_desc *d, int32_t coupled, double **Q3,
+                                   double **dQ3, double **dQ2fast, double **Q2, double **dQ2,
+                                   double t, double dt, double dt_fast, int32_t nstages,
+                                   const double *rka, const double *rkb, const double *rkc)
+{
+    if (!slow || !fast || n < 1 || !d || !Q3 || !dQ3 || !dQ2fast || !Q2 || !dQ2 || !rka || !rkb ||
+        !rkc || nstages < 1)
+        return CMDG_ERR_INVALID;
+    for (int i = 0; i < n; ++i)
+        if (!slow[i] || !fast[i]) return CMDG_ERR_INVALID;
+    return group_split_explicit_step(n, slow, fast, d, coupled, Q3, dQ3, dQ2fast, Q2, dQ2, t, dt,
+                                     dt_fast, nstages, rka, rkb, rkc);
 }
 
 }  // extern "C"

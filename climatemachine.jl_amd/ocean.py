@@ -298,6 +298,33 @@ class SplitExplicitSolver:
         self.dg_slow.synchronize()
         self.dg_fast.synchronize()
 
+    @staticmethod
+    def group_dostep(solvers, Q_slows, Q_fasts, nsteps=1):
+        """The same step for the per-rank solvers of one process whose slow models and fast
+        models are connected by ``dgmodel.connect_local`` (single-GPU rehearsal of the
+        partitioned run): ``cmdg_group_split_explicit_step``."""
+        from .dgmodel import _harr, _parr
+        s0 = solvers[0]
+        C, L, n = s0._C, s0.dg_slow.L, len(solvers)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        cast = lambda a: C.cast(a, C.c_void_p)
+        slow, fast = _harr([s.dg_slow for s in solvers]), _harr([s.dg_fast for s in solvers])
+        arr = [_parr(x) for x in (Q_slows, [s.dQ_slow for s in solvers],
+                                  [s.dQ2fast for s in solvers], Q_fasts,
+                                  [s.dQ_fast for s in solvers])]
+        s0.dg_slow._torch_ready()
+        for _ in range(int(nsteps)):
+            s0._lib.check(L.cmdg_group_split_explicit_step(
+                cast(slow), cast(fast), n, C.byref(s0.desc), int(s0.coupled), *[cast(a) for a in arr],
+                s0.t, s0.dt, s0.dt_fast, len(s0.RKA), p(s0.RKA), p(s0.RKB), p(s0.RKC)),
+                s0.dg_slow.handle)
+            for s in solvers:
+                s.steps += 1
+                s.t += s.dt
+        for s in solvers:
+            s.dg_slow.synchronize()
+            s.dg_fast.synchronize()
+
     # the exchange functions on their own (src/Ocean/SplitExplicit/Communication.jl)
     def initialize_states(self):
         self._lib.check(self.dg_slow.L.cmdg_ocean_initialize_states(

@@ -341,6 +341,16 @@ int cmdg_split_explicit_step(cmdg_handle slow, cmdg_handle fast,
                              double t, double dt_slow, double dt_fast, int32_t nstages,
                              const double *rka, const double *rkb, const double *rkc);
 
+/* the same step for n (slow, fast) pairs connected by cmdg_comm_connect_local (slow handles
+ * among themselves, fast handles among themselves), driven in lock step by one host thread; the
+ * element partition keeps whole columns, and slow[i] / fast[i] own the same columns */
+int cmdg_group_split_explicit_step(cmdg_handle *slow, cmdg_handle *fast, int32_t n,
+                                   const cmdg_ocean_coupling_desc *d, int32_t coupled,
+                                   double **Q_slow, double **dQ_slow, double **dQ2fast,
+                                   double **Q_fast, double **dQ_fast, double t, double dt_slow,
+                                   double dt_fast, int32_t nstages, const double *rka,
+                                   const double *rkb, const double *rkc);
+
 /* ---- measurement --------------------------------------------------------------- */
 enum {
     CMDG_K_GRADIENTS = 0, CMDG_K_DIVGRAD = 1, CMDG_K_GRADLAP = 2, CMDG_K_TENDENCY = 3,

@@ -264,7 +264,7 @@ def heat_eqn_setup(level=1, direction=0, N=4, rank=0, size=1):
     return law, grid, 0.01 / nsteps, nsteps
 
 
-def split_explicit_setup(coupled=True, Nx=5, Ny=5, Nz=8, N=4, N_extrusion=None):
+def split_explicit_setup(coupled=True, Nx=5, Ny=5, Nz=8, N=4, N_extrusion=None, rank=0, size=1):
     """test/Ocean/SplitExplicit/hydrostatic_spindown.jl:3-140 (SplitExplicitSolver variant):
     SimpleBox 1e6 x 1e6 x 400 m, 3-D HBModel (c_h = 1, alpha_T = kappa = 0, default Coriolis
     parameters but a Fixed box, so f = -0) + 2-D ShallowWaterModel (ConstantViscosity(nu_h),
@@ -277,9 +277,10 @@ def split_explicit_setup(coupled=True, Nx=5, Ny=5, Nz=8, N=4, N_extrusion=None):
     law2 = O.ShallowWaterModel(problem, law3.nu_h, advection=False, coupled=coupled, c=1.0)
     x, y = np.linspace(0.0, Lx, Nx + 1), np.linspace(0.0, Ly, Ny + 1)
     topl = M.StackedBrickTopology([x, y, np.linspace(-H, 0.0, Nz + 1)],
-                                  periodicity=(True, True, False), boundary=((0, 0), (0, 0), (1, 2)))
+                                  periodicity=(True, True, False), boundary=((0, 0), (0, 0), (1, 2)),
+                                  rank=rank, size=size)
     grid3 = M.DiscontinuousSpectralElementGrid(topl, N)
-    grid2 = O.extruded_barotropic_grid(x, y, N, N_extrusion=N_extrusion)
+    grid2 = O.extruded_barotropic_grid(x, y, N, N_extrusion=N_extrusion, rank=rank, size=size)
     return law3, grid3, law2, grid2
 
 

@@ -174,3 +174,72 @@ def test_shallow_water_alone_reproduces_reference_table(cm, oracle, torch, N_ext
     err = np.sqrt(oracle.weighted_norm2_local(grid, Qn, Qe) / oracle.weighted_norm2_local(grid, Qe))
     assert err < 0.005
     dg.close()
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_partitioned_split_explicit_matches_single_rank(cm, torch, size):
+    """The coupled stepper on a column partition (per-rank slow / fast pairs connected through
+    the local transport, driven by cmdg_group_split_explicit_step) against the one-rank run:
+    the flow deviation of ghost stacks is integrated from the received face pencils, so the
+    result does not depend on the partition."""
+    O = cm.ocean
+    central = cm.balancelaws.CentralNumericalFluxFirstOrder
+    law3, g3, law2, g2 = split_explicit_setup(True, Nx=4, Ny=3, Nz=3)
+    dg3 = cm.dgmodel.DGModel(law3, g3)
+    keep1 = O.install_hydrostatic_boussinesq_hooks(dg3)
+    dg2 = cm.dgmodel.DGModel(law2, g2, numerical_flux_first_order=central)
+    rng = np.random.default_rng(11)
+    Q3h = law3.init_state_prognostic(g3, dg3.state_auxiliary.cpu().numpy(), 600.0)
+    Q3h[:, 0:2] += 0.02 * rng.standard_normal(Q3h[:, 0:2].shape)
+    Q2h = law2.init_state_prognostic(g2, dg2.state_auxiliary.cpu().numpy(), 600.0)
+    by3 = {int(g): Q3h[i] for i, g in enumerate(g3.topology.globalelems[:g3.nreal])}
+    by2 = {int(g): Q2h[i] for i, g in enumerate(g2.topology.globalelems[:g2.nreal])}
+    Q3, Q2 = _gpu(torch, Q3h), _gpu(torch, Q2h)
+    se1 = O.SplitExplicitSolver(dg3, dg2, Q3, Q2, 1800.0, 300.0)
+    se1.dostep(Q3, Q2, 2)
+    ref3 = {int(g): Q3[i].cpu().numpy() for i, g in enumerate(g3.topology.globalelems[:g3.nreal])}
+    ref2 = {int(g): Q2[i].cpu().numpy() for i, g in enumerate(g2.topology.globalelems[:g2.nreal])}
+    refud = {int(g): dg3.state_auxiliary[i, 4:6].cpu().numpy()
+             for i, g in enumerate(g3.topology.globalelems[:g3.nreal])}
+    slows, fasts, Q3s, Q2s, grids, keeps = [], [], [], [], [], []
+    for r in range(size):
+        l3, gr3, l2, gr2 = split_explicit_setup(True, Nx=4, Ny=3, Nz=3, rank=r, size=size)
+        assert gr2.nreal * 3 == gr3.nreal and (gr3.nelem - gr3.nreal) == 3 * (gr2.nelem - gr2.nreal)
+        d3 = cm.dgmodel.DGModel(l3, gr3)
+        keeps.append(O.install_hydrostatic_boussinesq_hooks(d3))
+        d2 = cm.dgmodel.DGModel(l2, gr2, numerical_flux_first_order=central)
+        q3 = np.full((gr3.nelem, 4, gr3.Np), np.nan)
+        for i, g in enumerate(gr3.topology.globalelems[:gr3.nreal]):
+            q3[i] = by3[int(g)]
+        q2 = np.full((gr2.nelem, 3, gr2.Np), np.nan)
+        for i, g in enumerate(gr2.topology.globalelems[:gr2.nreal]):
+            q2[i] = by2[int(g)]
+        slows.append(d3)
+        fasts.append(d2)
+        grids.append((gr3, gr2))
+        Q3s.append(_gpu(torch, q3))
+        Q2s.append(_gpu(torch, q2))
+    cm.dgmodel.connect_local(slows)
+    cm.dgmodel.connect_local(fasts)
+    solvers = [O.SplitExplicitSolver(d3, d2, q3, q2, 1800.0, 300.0)
+               for d3, d2, q3, q2 in zip(slows, fasts, Q3s, Q2s)]
+    torch.cuda.synchronize()
+    O.SplitExplicitSolver.group_dostep(solvers, Q3s, Q2s, 2)
+    for (gr3, gr2), d3, q3, q2 in zip(grids, slows, Q3s, Q2s):
+        q3n, q2n, aud = q3.cpu().numpy(), q2.cpu().numpy(), d3.state_auxiliary[:, 4:6].cpu().numpy()
+        for i, g in enumerate(gr3.topology.globalelems[:gr3.nreal]):
+            for s in (0, 2):
+                sc = max(np.abs(ref3[int(g)][s]).max(), 1e-3)
+                assert np.abs(q3n[i, s] - ref3[int(g)][s]).max() / sc < 1e-11, (s, i)
+            assert np.abs(aud[i] - refud[int(g)]).max() < 1e-11
+        for i, g in enumerate(gr2.topology.globalelems[:gr2.nreal]):
+            for s in (0, 1):
+                sc = max(np.abs(ref2[int(g)][s]).max(), 1e-3)
+                assert np.abs(q2n[i, s] - ref2[int(g)][s]).max() / sc < 1e-11, (s, i)
+    for d3, k in zip(slows + [dg3], keeps + [keep1]):
+        d3.set_rhs_hooks()
+        for f in k:
+            f.close()
+        d3.close()
+    for d2 in fasts + [dg2]:
+        d2.close()
