@@ -180,6 +180,10 @@ def main():
     distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL prints a version banner on stdout at NCCL_DEBUG=VERSION; stdout carries the one
+        # JSON line of the contract
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device(dev))
 
