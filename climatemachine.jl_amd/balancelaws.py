@@ -23,6 +23,7 @@ PHYSICS_DRY_ATMOS = 2
 PHYSICS_HYDROSTATIC_BOUSSINESQ = 3
 PHYSICS_PRESSURE_GRADIENT = 4
 PHYSICS_SHALLOW_WATER = 5
+PHYSICS_MOIST_ATMOS = 6
 
 __all__ = [
     "EveryDirection", "HorizontalDirection", "VerticalDirection",

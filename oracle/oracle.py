@@ -65,6 +65,11 @@ def lib():
         _LIB.orc_advdiff_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _LIB.orc_sw_new.restype = C.POINTER(_Physics)
         _LIB.orc_sw_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _LIB.orc_moist_new.restype = C.POINTER(_Physics)
+        _LIB.orc_moist_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _LIB.orc_moist_saturation_adjustment.restype = C.c_double
+        _LIB.orc_moist_saturation_adjustment.argtypes = [C.POINTER(_Physics), C.c_double, C.c_double,
+                                                         C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB.orc_pgrad_new.restype = C.POINTER(_Physics)
         _LIB.orc_pgrad_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         if hasattr(_LIB, "orc_ocean_new"):
@@ -124,7 +129,7 @@ class OraclePhysics:
         self._ip = np.ascontiguousarray(ip, dtype=np.int32)
         self._dp = np.ascontiguousarray(dp, dtype=np.float64)
         ctor = {1: "orc_advdiff_new", 2: "orc_atmos_new", 3: "orc_ocean_new",
-                4: "orc_pgrad_new", 5: "orc_sw_new"}[law.physics_id]
+                4: "orc_pgrad_new", 5: "orc_sw_new", 6: "orc_moist_new"}[law.physics_id]
         self.c = getattr(lib(), ctor)(_p(self._ip), _p(self._dp), int(nf_first))
         ph = self.c.contents
         self.ns, self.naux, self.ngrad = ph.ns, ph.naux, ph.ngrad

@@ -366,3 +366,21 @@ def mms_atmos_setup(level=1, N=4):
                           boundary_conditions=(A.BC_INIT_STATE_MMS,), param_set=ps)
     nsteps = int(np.ceil(1.0 / (5e-3 / Ne)))
     return law, grid, 1.0 / nsteps, nsteps
+
+
+def density_current_setup(Ne=(100, 2, 50), N=4):
+    """test/Numerics/DGMethods/compressible_Navier_Stokes/density_current_model.jl:41-175:
+    12.8 km x 400 m x 6.4 km, 100 x 2 x 50 elements, periodic in y, default AtmosBC elsewhere,
+    EquilMoist (q_tot = 0), AnisoMinDiss(1), HydrostaticState(DryAdiabaticProfile(param_set)),
+    Gravity, Rusanov; dt = 0.01 s, ten LSRK54 steps."""
+    A, MO = cm.atmos, cm.moist
+    ps = MO.MoistParameters()
+    rng = [np.linspace(0.0, 12800.0, Ne[0] + 1), np.linspace(0.0, 400.0, Ne[1] + 1),
+           np.linspace(0.0, 6400.0, Ne[2] + 1)]
+    topl = M.StackedBrickTopology(rng, periodicity=(False, True, False),
+                                  boundary=((1, 1), (0, 0), (1, 1)))
+    grid = M.DiscontinuousSpectralElementGrid(topl, N)
+    law = MO.MoistAtmosModel(MO.DensityCurrentSetup(ps), A.DryAdiabaticProfile(ps, 290.0, 220.0),
+                             closure=MO.CLOSURE_ANISO_MIN_DISS, coefficient=1.0,
+                             boundary_conditions=(A.BC_ATMOS_DEFAULT,), param_set=ps)
+    return law, grid, 0.01, 10
