@@ -892,6 +892,7 @@ int cmdg_physics_counts(int32_t physics_id, const int32_t *iparam, int32_t out[6
     case CMDG_PHYSICS_HYDROSTATIC_BOUSSINESQ: return counts_ocean(iparam, out);
     case CMDG_PHYSICS_PRESSURE_GRADIENT: return counts_pgrad(iparam, out);
     case CMDG_PHYSICS_SHALLOW_WATER: return counts_sw(iparam, out);
+    case CMDG_PHYSICS_MOIST_ATMOS: return counts_moist(iparam, out);
     default: return CMDG_ERR_UNSUPPORTED;
     }
 }
@@ -917,6 +918,7 @@ int cmdg_create(const cmdg_desc *d, cmdg_handle *out)
     case CMDG_PHYSICS_HYDROSTATIC_BOUSSINESQ: e = make_engine_ocean(d, err); break;
     case CMDG_PHYSICS_PRESSURE_GRADIENT: e = make_engine_pgrad(d, err); break;
     case CMDG_PHYSICS_SHALLOW_WATER: e = make_engine_sw(d, err); break;
+    case CMDG_PHYSICS_MOIST_ATMOS: e = make_engine_moist(d, err); break;
     default: err = "unknown physics_id"; break;
     }
     if (!e) {

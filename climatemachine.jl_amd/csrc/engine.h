@@ -302,6 +302,8 @@ int counts_atmos(const int32_t *iparam, int32_t out[6]);
 EngineBase *make_engine_ocean(const cmdg_desc *d, std::string &err);
 int counts_ocean(const int32_t *iparam, int32_t out[6]);
 EngineBase *make_engine_sw(const cmdg_desc *d, std::string &err);
+EngineBase *make_engine_moist(const cmdg_desc *d, std::string &err);
+int counts_moist(const int32_t *iparam, int32_t out[6]);
 int counts_sw(const int32_t *iparam, int32_t out[6]);
 EngineBase *make_engine_pgrad(const cmdg_desc *d, std::string &err);
 int counts_pgrad(const int32_t *iparam, int32_t out[6]);

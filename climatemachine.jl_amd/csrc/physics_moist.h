@@ -1,0 +1,422 @@
+// Device functor for the moist LES configuration of AtmosModel: TotalEnergyModel + EquilMoist,
+// FlatOrientation, HydrostaticState (subtract_off), closure constant viscosity (0) /
+// SmagorinskyLilly (1) / AnisoMinDiss (2), source Gravity, default AtmosBC.  Restates
+//   src/Atmos/Model/AtmosModel.jl:397-520 (layouts), :625-690, :808-828,
+//   tendencies_{mass,momentum,energy,moisture}.jl + atmos_tendencies.jl (term order),
+//   moisture.jl:70-115 (EquilMoist), thermo_states.jl (PhaseEquil from (e_int, rho, q_tot); in
+//   this snapshot every flux evaluation re-runs the saturation adjustment, :40-60),
+//   src/Common/TurbulenceClosures/TurbulenceClosures.jl:411-497, :600-690.
+// Thermodynamics.jl 0.3.2 is not in the reference tree: mixture gas constant / heat capacities,
+// internal energy, saturation vapour pressure over liquid and ice, liquid fraction and the
+// saturation adjustment (Newton on e_int_sat(T) - e_int) restate its published formulation;
+// parity of saturated states is unpinned.  With q_tot = 0 every formula reduces operation by
+// operation to physics_atmos.h.
+//
+// State rho, rho u[3], rho e, rho q_tot; auxiliary coord[3], Phi, grad Phi[3], ref_state[7],
+// Delta, moisture (temperature, theta_v, q_liq, q_ice); gradient u[3], h_tot, theta_v, q_tot;
+// gradient flux grad h_tot[3], S[6] | grad u[9], N^2, grad q_tot[3].
+// Parameter block: see climatemachine.jl_amd/moist.py.
+#pragma once
+#include <math.h>
+
+#include "cmdg_common.h"
+
+namespace cmdg {
+
+struct MoistParams {
+    int subtract, kinematic, maxiter, src, nbc;
+    int bc[7];
+    double visc, R_d, cp_d, cv_d, T_0, grav, MSLP, invPr, tol;
+    double R_v, cp_v, cp_l, cp_i, LH_v0, LH_s0, T_triple, T_freeze, T_icenuc, p_triple, T_min;
+};
+
+template <int CLOSURE>
+struct MoistAtmos {
+    using Params = MoistParams;
+    static constexpr int OPHI = 3, OREF = 7, OTURB = 14, OMOIST = 15;
+    static constexpr int NGT = CLOSURE == 2 ? 10 : 7;  // turbulence block of the gradient flux
+    static constexpr int NS = 6, NAUX = 19, NGRAD = 6, NGF = 3 + NGT + 3, NGL = 0, NHYP = 0;
+    static constexpr bool HAS_UPDATE_AUX = true, FUSE_UPDATE_AUX = true, HAS_SOURCE = true;
+    static constexpr bool HAS_COURANT = false, HAS_PENALTY = false;
+    // entries the nodal refresh rewrites; read back by no kernel of the same evaluation
+    // (theta_v of the gradient argument is recomputed, see gradient_argument)
+    static constexpr int NUPD = 4;
+    __host__ __device__ static constexpr int upd_aux(int i) { return OMOIST + i; }
+    static constexpr int NDER = 0;
+    // minus-side auxiliary fields of the interface kernels: Phi, grad Phi, ref p, ref rho, Delta
+    static constexpr int NFAUX = 7;
+    __host__ __device__ static constexpr int face_aux(int i)
+    {
+        return i < 4 ? OPHI + i : (i == 4 ? OREF : (i == 5 ? OREF + 1 : OTURB));
+    }
+    __host__ __device__ static constexpr int hv_indexmap(int) { return 0; }
+    __host__ __device__ static bool needs_gradflux(const Params &) { return true; }
+    __host__ __device__ static bool update_aux_active(const Params &) { return true; }
+
+    static void make_params(Params &p, const int32_t *ip, const double *dp)
+    {
+        p.subtract = ip[1];
+        p.kinematic = ip[2];
+        p.maxiter = ip[3];
+        p.src = ip[5];
+        p.nbc = ip[6];
+        for (int i = 0; i < 7; ++i) p.bc[i] = ip[7 + i];
+        p.visc = dp[0];
+        p.R_d = dp[2];
+        p.cp_d = dp[3];
+        p.cv_d = dp[4];
+        p.T_0 = dp[5];
+        p.grav = dp[6];
+        p.MSLP = dp[7];
+        p.invPr = dp[8];
+        p.tol = dp[9];
+        p.R_v = dp[16];
+        p.cp_v = dp[17];
+        p.cp_l = dp[18];
+        p.cp_i = dp[19];
+        p.LH_v0 = dp[20];
+        p.LH_s0 = dp[21];
+        p.T_triple = dp[22];
+        p.T_freeze = dp[23];
+        p.T_icenuc = dp[24];
+        p.p_triple = dp[25];
+        p.T_min = dp[26];
+    }
+
+    // ---- Thermodynamics.jl: mixture properties ---------------------------------------
+    struct Thermo {
+        double T, q_tot, q_liq, q_ice, R_m, cv_m, cp_m;
+    };
+    __device__ static double cv_mix(const Params &m, double qt, double ql, double qi)
+    {
+        const double cv_v = m.cp_v - m.R_v;
+        return m.cv_d + (cv_v - m.cv_d) * qt + (m.cp_l - cv_v) * ql + (m.cp_i - cv_v) * qi;
+    }
+    __device__ static double e_int_v0(const Params &m) { return m.LH_v0 - m.R_v * m.T_0; }
+    __device__ static double e_int_i0(const Params &m) { return m.LH_s0 - m.LH_v0; }
+    __device__ static double internal_energy_T(const Params &m, double T, double qt, double ql,
+                                               double qi)
+    {
+        return cv_mix(m, qt, ql, qi) * (T - m.T_0) + (qt - ql) * e_int_v0(m) -
+               qi * (e_int_v0(m) + e_int_i0(m));
+    }
+    __device__ static double liquid_fraction(const Params &m, double T)
+    {
+        if (T > m.T_freeze) return 1.0;
+        if (T > m.T_icenuc) return (T - m.T_icenuc) / (m.T_freeze - m.T_icenuc);
+        return 0.0;
+    }
+    __device__ static double q_vap_saturation(const Params &m, double T, double rho)
+    {
+        const double lam = liquid_fraction(m, T);
+        const double LH_0 = lam * m.LH_v0 + (1 - lam) * m.LH_s0;
+        const double dcp = lam * (m.cp_v - m.cp_l) + (1 - lam) * (m.cp_v - m.cp_i);
+        const double pvs = m.p_triple * pow(T / m.T_triple, dcp / m.R_v) *
+                           exp((LH_0 - dcp * m.T_0) / m.R_v * (1 / m.T_triple - 1 / T));
+        return pvs / (rho * m.R_v * T);
+    }
+    __device__ static void phase_partition_equil(const Params &m, double T, double rho, double qt,
+                                                 double &ql, double &qi)
+    {
+        const double qvs = q_vap_saturation(m, T, rho);
+        const double qc = qt - qvs > 0 ? qt - qvs : 0.0;
+        const double lam = liquid_fraction(m, T);
+        ql = lam * qc;
+        qi = (1 - lam) * qc;
+    }
+    __device__ static double saturation_adjustment(const Params &m, double e_int, double rho,
+                                                   double qt)
+    {
+        double T = m.T_0 + (e_int - (qt - 0.0) * e_int_v0(m) + 0.0 * (e_int_v0(m) + e_int_i0(m))) /
+                               cv_mix(m, qt, 0.0, 0.0);
+        if (T < m.T_min) T = m.T_min;
+        if (qt <= q_vap_saturation(m, T, rho) && T > m.T_min) return T;
+        for (int it = 0; it < m.maxiter; ++it) {  // Newton on e_int_sat(T) - e_int
+            double ql, qi;
+            phase_partition_equil(m, T, rho, qt, ql, qi);
+            const double f = internal_energy_T(m, T, qt, ql, qi) - e_int;
+            const double lam = liquid_fraction(m, T);
+            const double qvs = q_vap_saturation(m, T, rho);
+            const double L = lam * m.LH_v0 + (1 - lam) * m.LH_s0;
+            const double dlam = (T > m.T_icenuc && T < m.T_freeze) ? 1 / (m.T_freeze - m.T_icenuc) : 0.0;
+            const double dqvs = qvs * L / (m.R_v * T * T);
+            const double cv_v = m.cp_v - m.R_v;
+            const double dcvm = cv_v - lam * m.cp_l - (1 - lam) * m.cp_i;
+            const double fp = cv_mix(m, qt, ql, qi) +
+                              (e_int_v0(m) + (1 - lam) * e_int_i0(m) + (T - m.T_0) * dcvm) * dqvs +
+                              (ql + qi) * e_int_i0(m) * dlam;
+            const double dT = f / fp;
+            T -= dT;
+            if (fabs(dT) < m.tol) break;
+        }
+        return T;
+    }
+    __device__ static double internal_energy(const double *Q, const double *aux)
+    {
+        const double rho = Q[0];
+        const double rhoinv = 1 / rho;
+        const double rhoe_kin = rhoinv * (Q[1] * Q[1] + Q[2] * Q[2] + Q[3] * Q[3]) / 2;
+        const double rhoe_pot = rho * aux[OPHI];
+        const double rhoe_int = Q[4] - rhoe_kin - rhoe_pot;
+        return rhoinv * rhoe_int;
+    }
+    // new_thermo_state(atmos, ::TotalEnergyModel, ::EquilMoist, state, aux)
+    __device__ static void thermo_state(const Params &m, const double *Q, const double *aux,
+                                        Thermo &ts)
+    {
+        const double e_int = internal_energy(Q, aux);
+        ts.q_tot = Q[5] / Q[0];
+        ts.T = saturation_adjustment(m, e_int, Q[0], ts.q_tot);
+        phase_partition_equil(m, ts.T, Q[0], ts.q_tot, ts.q_liq, ts.q_ice);
+        const double eps = m.R_v / m.R_d;
+        ts.R_m = m.R_d * (1 + (eps - 1) * ts.q_tot - eps * (ts.q_liq + ts.q_ice));
+        ts.cv_m = cv_mix(m, ts.q_tot, ts.q_liq, ts.q_ice);
+        ts.cp_m = m.cp_d + (m.cp_v - m.cp_d) * ts.q_tot + (m.cp_l - m.cp_v) * ts.q_liq +
+                  (m.cp_i - m.cp_v) * ts.q_ice;
+    }
+    __device__ static double air_pressure(const Thermo &ts, double rho) { return ts.R_m * rho * ts.T; }
+    __device__ static double virtual_pottemp(const Params &m, const Thermo &ts, double rho)
+    {
+        const double exner = pow(air_pressure(ts, rho) / m.MSLP, ts.R_m / ts.cp_m);
+        return ts.R_m / m.R_d * (ts.T / exner);
+    }
+
+    __device__ static void update_penalty(const Params &, double *, const double *, const double *,
+                                          const double *)
+    {
+    }
+    __device__ static double courant(const Params &, int, const double *, const double *,
+                                     const double *, double, double, double, int)
+    {
+        return 0.0;
+    }
+
+    // ---- fluxes ----------------------------------------------------------------------
+    __device__ static void flux_first_order(const Params &m, double *F, const double *Q,
+                                            const double *aux, double, int)
+    {
+        Thermo ts;
+        thermo_state(m, Q, aux, ts);
+        const double rho = Q[0];
+        const double p = air_pressure(ts, rho);
+        double u[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) u[d] = Q[1 + d] / rho;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) F[d] = Q[1 + d];
+        const double pp = m.subtract ? p - aux[OREF + 1] : p;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                F[d + 3 * (1 + c)] = Q[1 + d] * u[c] + (0.0 + (d == c ? pp : 0.0));
+#pragma unroll
+        for (int d = 0; d < 3; ++d) F[d + 12] = u[d] * Q[4] + u[d] * p;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) F[d + 15] = u[d] * Q[5];
+    }
+    __device__ static double sym(const double *c, int i, int j)
+    {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        return c[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)];
+    }
+    __device__ static void turbulence_tensors(const Params &m, const double *Q, const double *gf,
+                                              const double *aux, double *nu, double *tau)
+    {
+        double S[6], k[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) k[d] = aux[OPHI + 1 + d] / m.grav;
+        const double *T = gf + 3;
+        if constexpr (CLOSURE == 2) {  // gradient flux holds grad u: T[d + 3 c] = d u_c / d x_d
+            S[0] = T[0];
+            S[1] = (T[1] + T[3]) / 2;
+            S[2] = (T[2] + T[6]) / 2;
+            S[3] = T[4];
+            S[4] = (T[5] + T[7]) / 2;
+            S[5] = T[8];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) S[q] = T[q];
+        }
+        if constexpr (CLOSURE == 0) {
+            const double v = m.kinematic ? m.visc : m.visc / Q[0];
+            nu[0] = nu[1] = nu[2] = v;
+        } else {
+            const double N2 = T[NGT - 1];
+            const double norm2 = S[0] * S[0] + 2 * (S[1] * S[1]) + 2 * (S[2] * S[2]) + S[3] * S[3] +
+                                 2 * (S[4] * S[4]) + S[5] * S[5];
+            const double normS = sqrt(2 * norm2);
+            const double epsn = nextafter(fabs(normS), INFINITY) - fabs(normS);
+            const double Ri = N2 / (normS * normS + epsn);
+            double c = 1.0 - Ri * m.invPr;
+            c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+            const double fb2 = sqrt(c);
+            const double cd = m.visc * aux[OTURB];
+            double nu0;
+            if constexpr (CLOSURE == 1) {
+                nu0 = normS * (cd * cd) + 1e-5;
+            } else {  // AnisoMinDiss with an isotropic lengthscale: grad u_hat = grad u
+                double num = 0, den = 0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        double gg = 0;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) gg += T[r + 3 * i] * T[r + 3 * j];
+                        num += gg * sym(S, i, j);
+                        den += T[i + 3 * j] * T[i + 3 * j];
+                    }
+                double r = -num / (den + epsn);
+                if (r < 1e-5) r = 1e-5;
+                nu0 = (cd * cd) * r;
+            }
+            const double dk = nu0 * k[0] + nu0 * k[1] + nu0 * k[2];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double nv = k[d] * dk, nh = nu0 - nv;
+                nu[d] = nh + nv * fb2;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tau[d + 3 * c] = (-2 * nu[d]) * sym(S, d, c);
+    }
+    __device__ static void flux_second_order(const Params &m, double *F, const double *Q,
+                                             const double *gf, const double *, const double *aux,
+                                             double)
+    {
+        double nu[3], tau[9], dq[3];
+        turbulence_tensors(m, Q, gf, aux, nu, tau);
+        const double rho = Q[0];
+        const double *gq = gf + 3 + NGT;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) dq[d] = (-(nu[d] * m.invPr)) * gq[d];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) F[d] = dq[d] * rho;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                F[d + 3 * (1 + c)] = (0.0 + tau[d + 3 * c] * rho) + dq[d] * Q[1 + c];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double Dt = nu[d] * m.invPr;
+            F[d + 12] = (tau[d] * Q[1] + tau[d + 3] * Q[2] + tau[d + 6] * Q[3]) + (-Dt * gf[d]) * rho;
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) F[d + 15] = dq[d] * rho;
+    }
+    __device__ static void init_derived(const Params &, double *, const double *) {}
+    __device__ static void source(const Params &m, double *S, const double *Q, const double *,
+                                  const double *aux, const double *, double, int)
+    {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) S[q] = 0;
+        if (m.src & 1) {  // Gravity
+            const double r = m.subtract ? Q[0] - aux[OREF] : Q[0];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) S[1 + d] = -r * aux[OPHI + 1 + d];
+        }
+    }
+    __device__ static void gradient_argument(const Params &m, double *G, const double *Q,
+                                             const double *aux, double)
+    {
+        Thermo ts;
+        thermo_state(m, Q, aux, ts);
+        const double rhoinv = 1 / Q[0];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) G[d] = rhoinv * Q[1 + d];
+        const double e_tot = Q[4] * (1 / Q[0]);
+        G[3] = e_tot + ts.R_m * ts.T;
+        // transform.turbulence.theta_v = aux.moisture.theta_v: the nodal refresh of this same
+        // (Q, aux), evaluated here so that the fused refresh of neighbours is never read
+        G[4] = virtual_pottemp(m, ts, Q[0]);
+        G[5] = Q[5] * rhoinv;
+    }
+    __device__ static void gradient_flux(const Params &m, double *gf, const double *g,
+                                         const double *Q, const double *aux, double)
+    {
+        Thermo ts;
+        thermo_state(m, Q, aux, ts);
+        const double th = virtual_pottemp(m, ts, Q[0]);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gf[d] = g[d + 9];
+        double *T = gf + 3;
+        if constexpr (CLOSURE == 2) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) T[q] = g[q];
+        } else {
+            T[0] = g[0 + 3 * 0];
+            T[1] = (g[1 + 3 * 0] + g[0 + 3 * 1]) / 2;
+            T[2] = (g[2 + 3 * 0] + g[0 + 3 * 2]) / 2;
+            T[3] = g[1 + 3 * 1];
+            T[4] = (g[2 + 3 * 1] + g[1 + 3 * 2]) / 2;
+            T[5] = g[2 + 3 * 2];
+        }
+        T[NGT - 1] = (g[0 + 3 * 4] * aux[OPHI + 1] + g[1 + 3 * 4] * aux[OPHI + 2] +
+                      g[2 + 3 * 4] * aux[OPHI + 3]) / th;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gf[3 + NGT + d] = g[d + 15];
+    }
+    __device__ static void post_gradient_laplacian(const Params &, double *, const double *,
+                                                   const double *, const double *, double)
+    {
+    }
+    __device__ static void wavespeed(const Params &m, double *ws, const double *n, const double *Q,
+                                     const double *aux, double, int)
+    {
+        Thermo ts;
+        thermo_state(m, Q, aux, ts);
+        const double rhoinv = 1 / Q[0];
+        const double uN =
+            fabs(n[0] * (rhoinv * Q[1]) + n[1] * (rhoinv * Q[2]) + n[2] * (rhoinv * Q[3]));
+        const double gamma = ts.cp_m / ts.cv_m;
+        const double ss = sqrt(gamma * ts.R_m * ts.T);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) ws[s] = uN + ss;
+    }
+    // EquilMoist atmos_nodal_update_auxiliary_state! (moisture.jl:85-98)
+    __device__ static void update_aux(const Params &m, const double *Q, double *aux, double)
+    {
+        Thermo ts;
+        thermo_state(m, Q, aux, ts);
+        aux[OMOIST] = ts.T;
+        aux[OMOIST + 1] = virtual_pottemp(m, ts, Q[0]);
+        aux[OMOIST + 2] = ts.q_liq;
+        aux[OMOIST + 3] = ts.q_ice;
+    }
+    __device__ static void boundary_state(const Params &m, int kind, int bctag, double *QP,
+                                          double *auxP, const double *n, const double *QM,
+                                          const double *, double t, const double *, const double *)
+    {
+        if (m.bc[bctag - 1] == 1) {  // Impenetrable(FreeSlip), Insulating, Impermeable
+            const double dn = QM[1] * n[0] + QM[2] * n[1] + QM[3] * n[2];
+            const double f = kind == BS_FIRST ? 2 * dn : dn;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) QP[1 + d] -= f * n[d];
+        }
+        update_aux(m, QP, auxP, t);
+    }
+    __device__ static void boundary_flux_second_order(const Params &, int, double *, double *,
+                                                      double *, double *, double *, const double *,
+                                                      const double *, const double *,
+                                                      const double *, const double *, double,
+                                                      const double *, const double *,
+                                                      const double *)
+    {
+    }
+    __device__ static void boundary_state_divergence(const Params &, int, double *, double *,
+                                                     const double *, const double *,
+                                                     const double *, double)
+    {
+    }
+    __device__ static void boundary_state_higher_order(const Params &, int, double *, double *,
+                                                       double *, const double *, const double *,
+                                                       const double *, const double *, double)
+    {
+    }
+};
+
+}  // namespace cmdg

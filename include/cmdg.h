@@ -44,8 +44,10 @@ enum {
     CMDG_PHYSICS_ADVECTION_DIFFUSION = 1, CMDG_PHYSICS_DRY_ATMOS = 2,
     CMDG_PHYSICS_HYDROSTATIC_BOUSSINESQ = 3,
     CMDG_PHYSICS_PRESSURE_GRADIENT = 4, /* PressureGradientModel, ref_state.jl:196-233 */
-    CMDG_PHYSICS_SHALLOW_WATER = 5      /* ShallowWaterModel (barotropic half of the split-explicit
+    CMDG_PHYSICS_SHALLOW_WATER = 5,     /* ShallowWaterModel (barotropic half of the split-explicit
                                            ocean), on a one-layer extrusion of the 2-D grid */
+    CMDG_PHYSICS_MOIST_ATMOS = 6        /* AtmosModel LES configuration with EquilMoist
+                                           (src/Atmos/Model/moisture.jl:70-115) */
 };
 
 /* Construction record: the fields of `DGModel(balance_law, grid, nf1, nf2, nfgrad;

@@ -1,0 +1,122 @@
+"""Moist LES law (EquilMoist) on the GPU: the HIP functor against the oracle for the dry limit
+and for a cloudy bubble with each closure, at N = 4 and N = 6, and the reference's
+density-current number (density_current_model.jl:247) end to end on the device.  ``-m gpu``."""
+import numpy as np
+import pytest
+
+from helpers import density_current_setup, rel_linf, rising_bubble_setup
+from test_moist_oracle import moist_twin_of_bubble
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "no HIP device: the product path has no CPU fallback"
+    return t
+
+
+def _gpu(torch, a):
+    x = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    torch.cuda.synchronize()
+    return x
+
+
+def _cloudy(cm, closure, N=4, nx=3):
+    A, MO = cm.atmos, cm.moist
+    _, grid = rising_bubble_setup(nx=nx, ny=2, nz=nx, N=N)
+    ps = MO.MoistParameters()
+    # converged saturation adjustment: with the package's default tolerance (0.1 K) the number
+    # of Newton steps -- and with it the temperature, to 1e-3 K -- depends on last-bit
+    # differences of exp / pow between host and device
+    law = MO.MoistAtmosModel(MO.MoistBubbleSetup(ps, xc=250.0 * nx, zc=250.0 * nx, rc=200.0 * nx),
+                             A.DryAdiabaticProfile(ps, 300.0, 0.0), closure=closure,
+                             coefficient={0: 75.0, 1: ps.C_smag, 2: 1.0}[closure],
+                             param_set=ps, maxiter=40, tolerance=1e-11)
+    return law, grid
+
+
+@pytest.mark.parametrize("closure", [0, 1, 2])
+def test_moist_tendency_and_aux_match_oracle(cm, oracle, torch, closure):
+    law, grid = _cloudy(cm, closure)
+    odg = oracle.OracleDGModel(law, grid)
+    dg = cm.dgmodel.DGModel(law, grid)
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    rng = np.random.default_rng(closure)
+    Q0[:, 1:4] += Q0[:, 0:1] * 2.0 * rng.standard_normal(Q0[:, 1:4].shape)
+    T0 = rng.standard_normal(Q0.shape)
+    for alpha, beta in ((1.0, 0.0), (0.5, 2.0)):
+        To = T0.copy()
+        odg(To, Q0.copy(), 0.0, alpha, beta)
+        Tg = _gpu(torch, T0)
+        dg(Tg, _gpu(torch, Q0), 0.0, alpha, beta)
+        Tn = Tg.cpu().numpy()
+        for s in range(6):
+            assert rel_linf(Tn[:, s], To[:, s]) < 1e-11, s
+        gfg = dg.state_gradient_flux.cpu().numpy()
+        for s in range(law.ngradflux):
+            sc = max(np.abs(odg.state_gradient_flux[:, s]).max(), 1e-300)
+            assert np.abs(gfg[:, s] - odg.state_gradient_flux[:, s]).max() / sc < 1e-11, s
+    auxg = dg.state_auxiliary.cpu().numpy()
+    assert odg.state_auxiliary[:, 17].max() > 1e-4                # cloudy: q_liq
+    for c in (15, 16, 17, 18):
+        sc = max(np.abs(odg.state_auxiliary[:, c]).max(), 1e-300)
+        assert np.abs(auxg[:, c] - odg.state_auxiliary[:, c]).max() / sc < 1e-11, c
+    Qo, dQo = Q0.copy(), np.zeros_like(Q0)
+    for i in range(2):
+        oracle.lsrk54_step(odg, Qo, dQo, i * 0.02, 0.02)
+    Q = _gpu(torch, Q0)
+    dQ = torch.zeros_like(Q)
+    dg.lsrk_run(Q, dQ, 0.0, 0.02, 2, oracle.RKA, oracle.RKB, oracle.RKC)
+    dg.synchronize()
+    for s in range(6):
+        assert rel_linf(Q.cpu().numpy()[:, s], Qo[:, s]) < 1e-11, s
+    dg.close()
+
+
+def test_moist_dry_limit_on_the_device(cm, oracle, torch):
+    """q_tot = 0: the moist functor gives the dry functor's tendencies."""
+    lawd, lawm, grid = moist_twin_of_bubble()
+    dgd, dgm = cm.dgmodel.DGModel(lawd, grid), cm.dgmodel.DGModel(lawm, grid)
+    rng = np.random.default_rng(0)
+    Q0 = lawd.init_state_prognostic(grid, dgd.state_auxiliary.cpu().numpy(), 0.0)
+    Q0[:, 1:4] += Q0[:, 0:1] * 3 * rng.standard_normal(Q0[:, 1:4].shape)
+    Qm = np.concatenate([Q0, np.zeros_like(Q0[:, :1])], axis=1)
+    Td, Tm = _gpu(torch, np.zeros_like(Q0)), _gpu(torch, np.zeros_like(Qm))
+    dgd(Td, _gpu(torch, Q0), 0.0, 1.0, 0.0)
+    dgm(Tm, _gpu(torch, Qm), 0.0, 1.0, 0.0)
+    assert rel_linf(Tm.cpu().numpy()[:, :5], Td.cpu().numpy()) < 1e-13
+    assert not Tm.cpu().numpy()[:, 5].any()
+    dgd.close()
+    dgm.close()
+
+
+def test_moist_order_six_matches_oracle(cm, oracle, torch):
+    law, grid = _cloudy(cm, 1, N=6, nx=2)
+    odg = oracle.OracleDGModel(law, grid)
+    dg = cm.dgmodel.DGModel(law, grid)
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    To = np.zeros_like(Q0)
+    odg(To, Q0.copy(), 0.0, 1.0, 0.0)
+    Tg = _gpu(torch, np.zeros_like(Q0))
+    dg(Tg, _gpu(torch, Q0), 0.0, 1.0, 0.0)
+    for s in range(6):
+        assert rel_linf(Tg.cpu().numpy()[:, s], To[:, s]) < 1e-11, s
+    dg.close()
+
+
+def test_density_current_reference_number_on_the_device(cm, torch):
+    law, grid, dt, nsteps = density_current_setup()
+    dg = cm.dgmodel.DGModel(law, grid)
+    Q = dg.init_ode_state(0.0)
+    eng0 = dg.norm(Q)
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+    solver.dostep(Q, nsteps=nsteps)
+    dg.synchronize()
+    ratio = dg.norm(Q) / eng0
+    ref = 9.9999970927037096e-01
+    assert abs(ratio - ref) <= 1.5e-8 * ref
+    assert abs((1 - ratio) - (1 - ref)) <= 2e-4 * (1 - ref)
+    dg.close()
