@@ -29,7 +29,7 @@ class CmdgDesc(C.Structure):
         ("dim", C.c_int32), ("N", C.c_int32 * 3),
         ("nreal", C.c_int64), ("nghost", C.c_int64),
         ("nvgeo", C.c_int32), ("physics_id", C.c_int32),
-        ("iparam", C.c_int32 * 16), ("dparam", C.c_double * 32),
+        ("iparam", C.c_int32 * 16), ("dparam", C.c_double * 64),
         ("nf_first", C.c_int32), ("direction", C.c_int32),
         ("diffusion_direction", C.c_int32), ("stacked", C.c_int32),
         ("vgeo", C.c_void_p), ("sgeo", C.c_void_p),

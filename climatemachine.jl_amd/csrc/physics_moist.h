@@ -28,6 +28,9 @@ struct MoistParams {
     int bc[7];
     double visc, R_d, cp_d, cv_d, T_0, grav, MSLP, invPr, tol;
     double R_v, cp_v, cp_l, cp_i, LH_v0, LH_s0, T_triple, T_freeze, T_icenuc, p_triple, T_min;
+    // BOMEX (experiments/AtmosLES/bomex_model.jl:76-246, 352-470): surface fluxes and sources
+    double u_star, e_flux, q_flux, f_cor, u_geo, u_slope, v_geo, z_sponge, a_max, gam, z_max;
+    double dqt_peak, zl_m, zh_m, dth_peak, zl_sub, zh_sub, w_sub;
 };
 
 template <int CLOSURE>
@@ -81,6 +84,24 @@ struct MoistAtmos {
         p.T_icenuc = dp[24];
         p.p_triple = dp[25];
         p.T_min = dp[26];
+        p.u_star = dp[32];
+        p.e_flux = dp[33];
+        p.q_flux = dp[34];
+        p.f_cor = dp[35];
+        p.u_geo = dp[36];
+        p.u_slope = dp[37];
+        p.v_geo = dp[38];
+        p.z_sponge = dp[39];
+        p.a_max = dp[40];
+        p.gam = dp[41];
+        p.z_max = dp[42];
+        p.dqt_peak = dp[43];
+        p.zl_m = dp[44];
+        p.zh_m = dp[45];
+        p.dth_peak = dp[46];
+        p.zl_sub = dp[47];
+        p.zh_sub = dp[48];
+        p.w_sub = dp[49];
     }
 
     // ---- Thermodynamics.jl: mixture properties ---------------------------------------
@@ -309,15 +330,84 @@ struct MoistAtmos {
         for (int d = 0; d < 3; ++d) F[d + 15] = dq[d] * rho;
     }
     __device__ static void init_derived(const Params &, double *, const double *) {}
-    __device__ static void source(const Params &m, double *S, const double *Q, const double *,
+    // sources in the order of the model's tuple: Gravity, BomexTendencies, BomexSponge,
+    // BomexGeostrophic (bomex_model.jl:396-420)
+    __device__ static void source(const Params &m, double *S, const double *Q, const double *gf,
                                   const double *aux, const double *, double, int)
     {
 #pragma unroll
         for (int q = 0; q < 6; ++q) S[q] = 0;
+        const double rho = Q[0];
+        double k[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) k[d] = aux[OPHI + 1 + d] / m.grav;
+        const double z = aux[OPHI] / m.grav;
+        bool first = true;
         if (m.src & 1) {  // Gravity
-            const double r = m.subtract ? Q[0] - aux[OREF] : Q[0];
+            const double r = m.subtract ? rho - aux[OREF] : rho;
 #pragma unroll
             for (int d = 0; d < 3; ++d) S[1 + d] = -r * aux[OPHI + 1 + d];
+            first = false;
+        }
+        if (m.src & 2) {  // BomexTendencies (:141-246)
+            double rdqt, rdth, w_s = -0.0;
+            const double lm = (z - m.zl_m) / (m.zh_m - m.zl_m);
+            if (z <= m.zl_m)
+                rdqt = rho * m.dqt_peak;
+            else if (z <= m.zh_m)
+                rdqt = rho * (m.dqt_peak - m.dqt_peak * lm);
+            else
+                rdqt = -0.0;
+            const double lt = (z - m.zl_sub) / (m.z_max - m.zl_sub);
+            if (z <= m.zl_sub)
+                rdth = rho * m.dth_peak;
+            else if (z <= m.z_max)
+                rdth = rho * (m.dth_peak - m.dth_peak * lt);
+            else
+                rdth = -0.0;
+            const double ls = (z - m.zl_sub) / (m.zh_sub - m.zl_sub);
+            if (z <= m.zl_sub)
+                w_s = -0.0 + z * (m.w_sub) / (m.zl_sub);
+            else if (z <= m.zh_sub)
+                w_s = m.w_sub - (m.w_sub) * ls;
+            const double *gq = gf + 3 + NGT;
+            const double kq = k[0] * gq[0] + k[1] * gq[1] + k[2] * gq[2];
+            const double kh = k[0] * gf[0] + k[1] * gf[1] + k[2] * gf[2];
+            S[0] = rdqt - rho * w_s * kq;
+            S[5] = rdqt - rho * w_s * kq;
+            Thermo ts;
+            thermo_state(m, Q, aux, ts);
+            const double exner = pow(air_pressure(ts, rho) / m.MSLP, ts.R_m / ts.cp_m);
+            const double term1 = ts.cv_m * rdth * exner + e_int_v0(m) * rdqt;
+            const double term2 = rho * w_s * kh;
+            S[4] = term1 - term2;
+        }
+        const double ug[3] = {m.u_geo + m.u_slope * z, m.v_geo, 0.0};
+        if (m.src & 4) {  // BomexSponge (:106-133)
+            double v[3] = {0, 0, 0};
+            if (m.z_sponge <= z) {
+                const double r = (z - m.z_sponge) / (m.z_max - m.z_sponge);
+                const double sp = sin(3.14159265358979323846 * (r / 2));
+                const double beta = m.a_max * (m.gam == 2 ? sp * sp : pow(sp, m.gam));
+#pragma unroll
+                for (int d = 0; d < 3; ++d) v[d] = -beta * (Q[1 + d] - rho * ug[d]);
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) S[1 + d] = first ? v[d] : S[1 + d] + v[d];
+            first = false;
+        }
+        if (m.src & 8) {  // BomexGeostrophic: -(f k) x (rho u - rho u_geo) (:79-104)
+            double a[3], b[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                a[d] = m.f_cor * k[d];
+                b[d] = Q[1 + d] - rho * ug[d];
+            }
+            const double c[3] = {-(a[1] * b[2] - a[2] * b[1]), -(a[2] * b[0] - a[0] * b[2]),
+                                 -(a[0] * b[1] - a[1] * b[0])};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) S[1 + d] = first ? c[d] : S[1 + d] + c[d];
+            first = false;
         }
     }
     __device__ static void gradient_argument(const Params &m, double *G, const double *Q,
@@ -391,7 +481,8 @@ struct MoistAtmos {
                                           double *auxP, const double *n, const double *QM,
                                           const double *, double t, const double *, const double *)
     {
-        if (m.bc[bctag - 1] == 1) {  // Impenetrable(FreeSlip), Insulating, Impermeable
+        const int bc = m.bc[bctag - 1];
+        if (bc == 1 || bc == 2) {  // Impenetrable: FreeSlip; DragLaw reflects the same way
             const double dn = QM[1] * n[0] + QM[2] * n[1] + QM[3] * n[2];
             const double f = kind == BS_FIRST ? 2 * dn : dn;
 #pragma unroll
@@ -399,13 +490,39 @@ struct MoistAtmos {
         }
         update_aux(m, QP, auxP, t);
     }
-    __device__ static void boundary_flux_second_order(const Params &, int, double *, double *,
-                                                      double *, double *, double *, const double *,
+    // normal_boundary_flux_second_order! of AtmosBC: the default conditions add nothing; the
+    // BOMEX surface adds the drag-law stress (bc_momentum.jl:103-118), the prescribed energy flux
+    // (bc_energy.jl:87-99) and the prescribed moisture flux (bc_moisture.jl:38-52).  They are
+    // normal fluxes X; the kernel forms F . n, so F = X n.
+    __device__ static void boundary_flux_second_order(const Params &m, int bctag, double *F,
+                                                      double *, double *, double *, double *,
+                                                      const double *n, const double *QM,
                                                       const double *, const double *,
-                                                      const double *, const double *, double,
-                                                      const double *, const double *,
-                                                      const double *)
+                                                      const double *, double, const double *Q1,
+                                                      const double *, const double *)
     {
+        if (m.bc[bctag - 1] != 2) return;
+        double X[6] = {0, 0, 0, 0, 0, 0};
+        double u1[3], ut[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) u1[d] = Q1[1 + d] / Q1[0];
+        const double un = u1[0] * n[0] + u1[1] * n[1] + u1[2] * n[2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) ut[d] = u1[d] - un * n[d];
+        const double nut = sqrt(ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2]);
+        const double Cd = (m.u_star / nut) * (m.u_star / nut);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) X[1 + d] += QM[0] * (Cd * nut * ut[d]);
+        X[4] -= m.e_flux;
+        const double nrd = -m.q_flux;
+        X[0] += nrd;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) X[1 + d] += nrd / QM[0] * QM[1 + d];
+        X[5] += nrd;
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) F[d + 3 * s] += X[s] * n[d];
     }
     __device__ static void boundary_state_divergence(const Params &, int, double *, double *,
                                                      const double *, const double *,

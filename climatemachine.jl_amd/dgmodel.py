@@ -92,7 +92,7 @@ class DGModel:
         d.nvgeo = g.vgeo.shape[1]
         d.physics_id = law.physics_id
         d.iparam[:] = [int(v) for v in ip]
-        d.dparam[:] = [float(v) for v in dp]
+        d.dparam[:] = [float(v) for v in dp] + [0.0] * (64 - len(dp))
         d.nf_first = int(numerical_flux_first_order)
         d.direction, d.diffusion_direction = int(self.direction), int(self.diffusion_direction)
         d.stacked = int(bool(g.topology.isstacked))

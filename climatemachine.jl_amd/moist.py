@@ -24,9 +24,14 @@ from .balancelaws import PHYSICS_MOIST_ATMOS
 from .mesh import grids as G
 
 __all__ = ["MoistParameters", "MoistAtmosModel", "DensityCurrentSetup", "MoistBubbleSetup",
+           "BomexSetup", "bomex_model", "SRC_BOMEX_TENDENCIES", "SRC_BOMEX_SPONGE",
+           "SRC_BOMEX_GEOSTROPHIC", "BC_BOMEX_SURFACE",
            "CLOSURE_CONSTANT", "CLOSURE_SMAGORINSKY", "CLOSURE_ANISO_MIN_DISS"]
 
 CLOSURE_CONSTANT, CLOSURE_SMAGORINSKY, CLOSURE_ANISO_MIN_DISS = 0, 1, 2
+# source bits next to SRC_GRAVITY = 1 and the boundary kind of the BOMEX surface
+SRC_BOMEX_TENDENCIES, SRC_BOMEX_SPONGE, SRC_BOMEX_GEOSTROPHIC = 2, 4, 8
+BC_BOMEX_SURFACE = 2
 
 
 class MoistParameters(PlanetParameters):
@@ -51,6 +56,95 @@ class MoistParameters(PlanetParameters):
         e_v0 = self.LH_v0 - self.R_v * self.T_0
         e_i0 = self.LH_s0 - self.LH_v0
         return self.cv_m(qt, ql, qi) * (T - self.T_0) + (qt - ql) * e_v0 - qi * (e_v0 + e_i0)
+
+
+class BomexSetup:
+    """``init_bomex!`` of experiments/AtmosLES/bomex_model.jl:252-345: piecewise-linear
+    ``theta_liq`` and ``q_tot`` profiles, zonal wind -8.75 m/s sheared above 700 m, pressure
+    ``P_sfc exp(-z / H)``; the thermodynamic state comes from ``PhaseEquil_pthetaq`` (restated:
+    ``theta_liq_ice(T, p, q_equil(T, p)) = theta`` solved for ``T`` by bisection)."""
+
+    def __init__(self, ps):
+        self.ps = ps
+
+    def thermo_from_p_theta_q(self, p, theta, qt):
+        ps = self.ps
+
+        def state(T):
+            # equilibrium partition at (T, p): rho depends on the partition, two sweeps suffice
+            ql = np.zeros_like(T)
+            qi = np.zeros_like(T)
+            for _ in range(3):
+                Rm = ps.R_d * (1 + (ps.R_v / ps.R_d - 1) * qt - ps.R_v / ps.R_d * (ql + qi))
+                rho = p / (Rm * T)
+                lam = np.clip((T - ps.T_icenuc) / (ps.T_freeze - ps.T_icenuc), 0.0, 1.0)
+                LH0 = lam * ps.LH_v0 + (1 - lam) * ps.LH_s0
+                dcp = lam * (ps.cp_v - ps.cp_l) + (1 - lam) * (ps.cp_v - ps.cp_i)
+                pvs = ps.press_triple * (T / ps.T_triple) ** (dcp / ps.R_v) * np.exp(
+                    (LH0 - dcp * ps.T_0) / ps.R_v * (1 / ps.T_triple - 1 / T))
+                qc = np.maximum(qt - pvs / (rho * ps.R_v * T), 0.0)
+                ql, qi = lam * qc, (1 - lam) * qc
+            cpm = ps.cp_d + (ps.cp_v - ps.cp_d) * qt + (ps.cp_l - ps.cp_v) * ql + (ps.cp_i - ps.cp_v) * qi
+            Lv = ps.LH_v0 + (ps.cp_v - ps.cp_l) * (T - ps.T_0)
+            Ls = ps.LH_s0 + (ps.cp_v - ps.cp_i) * (T - ps.T_0)
+            th = T / (p / ps.MSLP) ** (Rm / cpm) * (1 - (Lv * ql + Ls * qi) / (cpm * T))
+            return th, rho, ql, qi
+
+        lo, hi = 150.0 + 0 * theta, 400.0 + 0 * theta
+        for _ in range(80):
+            mid = (lo + hi) / 2
+            th = state(mid)[0]
+            lo = np.where(th < theta, mid, lo)
+            hi = np.where(th < theta, hi, mid)
+        T = (lo + hi) / 2
+        _, rho, ql, qi = state(T)
+        return T, rho, ql, qi
+
+    def __call__(self, law, aux, coord, t):
+        ps = self.ps
+        z = coord[2]
+        P_sfc, qg, T_sfc = 1.015e5, 22.45e-3, 300.4
+        Rm_sfc = ps.R_d * (1 + (ps.R_v / ps.R_d - 1) * qg)
+        zl1, zl2, zl3, zl4 = 520.0, 1480.0, 2000.0, 3000.0
+        th = np.where(z <= zl1, 298.7,
+             np.where(z <= zl2, 298.7 + (z - zl1) * (302.4 - 298.7) / (zl2 - zl1),
+             np.where(z <= zl3, 302.4 + (z - zl2) * (308.2 - 302.4) / (zl3 - zl2),
+                      308.2 + (z - zl3) * (311.85 - 308.2) / (zl4 - zl3))))
+        qt = np.where(z <= zl1, 17.0 + (z / zl1) * (16.3 - 17.0),
+             np.where(z <= zl2, 16.3 + (z - zl1) * (10.7 - 16.3) / (zl2 - zl1),
+             np.where(z <= zl3, 10.7 + (z - zl2) * (4.2 - 10.7) / (zl3 - zl2),
+                      4.2 + (z - zl3) * (3.0 - 4.2) / (zl4 - zl3)))) / 1000
+        u = np.where(z <= 700.0, -8.75, -8.75 + (z - 700.0) * (-4.61 + 8.75) / (zl4 - 700.0))
+        P = P_sfc * np.exp(-z / (Rm_sfc * T_sfc / ps.grav))
+        T, rho, ql, qi = self.thermo_from_p_theta_q(P, th, qt)
+        e_int = ps.internal_energy(T, qt, ql, qi)
+        rhoe = rho * (0.5 * u * u + ps.grav * z + e_int)
+        zero = 0.0 * rho
+        return rho, [rho * u, zero, zero], rhoe, rho * qt
+
+
+def bomex_model(zmax=3000.0, param_set=None, closure=CLOSURE_SMAGORINSKY):
+    """``bomex_model(FT, config_type, zmax, "prescribed")`` (bomex_model.jl:347-470): EquilMoist
+    (maxiter 5, tolerance 0.1), SmagorinskyLilly(0.23), the default reference state
+    HydrostaticState(DecayingTemperatureProfile(param_set)), sources Gravity + BomexTendencies +
+    BomexSponge + BomexGeostrophic, surface Impenetrable(DragLaw(u_star = 0.28)) with prescribed
+    energy (LHF + SHF) and moisture (LHF / L_v(T_sfc)) fluxes, default AtmosBC at the top."""
+    from .atmos import DecayingTemperatureProfile
+    ps = param_set or MoistParameters()
+    ref = DecayingTemperatureProfile(ps, 290.0, 220.0, ps.R_d * 290.0 / ps.grav)
+    law = MoistAtmosModel(BomexSetup(ps), ref, closure=closure, coefficient=0.23,
+                          sources=SRC_GRAVITY | SRC_BOMEX_TENDENCIES | SRC_BOMEX_SPONGE
+                          | SRC_BOMEX_GEOSTROPHIC,
+                          boundary_conditions=(BC_BOMEX_SURFACE, BC_ATMOS_DEFAULT), param_set=ps,
+                          maxiter=5, tolerance=0.1)
+    LHF, SHF, T_sfc = 147.2, 9.5, 300.4
+    Lv = ps.LH_v0 + (ps.cp_v - ps.cp_l) * (T_sfc - ps.T_0)
+    law.bomex = dict(u_star=0.28, e_flux=LHF + SHF, q_flux=LHF / Lv, f_coriolis=0.376e-4,
+                     u_geostrophic=-10.0, u_slope=1.8e-3, v_geostrophic=0.0, z_sponge=2400.0,
+                     alpha_max=0.75, gamma=2.0, z_max=float(zmax), dqt_peak=-1.2e-8,
+                     zl_moisture=300.0, zh_moisture=500.0, dtheta_peak=-2 / ps.day, zl_sub=1500.0,
+                     zh_sub=2100.0, w_sub=-0.65e-2)
+    return law
 
 
 class DensityCurrentSetup:
@@ -138,11 +232,17 @@ class MoistAtmosModel:
         ip[5], ip[6] = self.sources, len(self.boundary_conditions)
         for i, bc in enumerate(self.boundary_conditions):
             ip[7 + i] = bc
-        dp = np.zeros(32)
+        dp = np.zeros(64)
         dp[0] = self.coefficient
         dp[2:10] = [ps.R_d, ps.cp_d, ps.cv_d, ps.T_0, ps.grav, ps.MSLP, ps.inv_Pr_turb, self.tolerance]
         dp[16:27] = [ps.R_v, ps.cp_v, ps.cp_l, ps.cp_i, ps.LH_v0, ps.LH_s0, ps.T_triple, ps.T_freeze,
                      ps.T_icenuc, ps.press_triple, ps.T_min]
+        b = getattr(self, "bomex", None)
+        if b:
+            dp[32:50] = [b[k] for k in (
+                "u_star", "e_flux", "q_flux", "f_coriolis", "u_geostrophic", "u_slope",
+                "v_geostrophic", "z_sponge", "alpha_max", "gamma", "z_max", "dqt_peak",
+                "zl_moisture", "zh_moisture", "dtheta_peak", "zl_sub", "zh_sub", "w_sub")]
         return ip, dp
 
     def init_state_auxiliary(self, grid):

@@ -63,7 +63,7 @@ typedef struct cmdg_desc {
     int32_t nvgeo;               /* columns of vgeo (25: GeometricFactors.jl:60-67) */
     int32_t physics_id;          /* CMDG_PHYSICS_* */
     int32_t iparam[16];          /* law parameters, see csrc/physics_*.h */
-    double dparam[32];
+    double dparam[64];
     int32_t nf_first;            /* CMDG_RUSANOV | CMDG_CENTRAL_FIRST_ORDER */
     int32_t direction;           /* dg.direction */
     int32_t diffusion_direction; /* dg.diffusion_direction */

@@ -21,7 +21,9 @@
  * Gradient flux grad h_tot[3], S[6] | grad u[9], N^2, grad q_tot[3].
  *
  * iparam[0] closure, [1] subtract_off, [2] kinematic viscosity (closure 0), [3] maxiter,
- * [5] sources (1 Gravity), [6] nbc, [7..13] bc kinds (1 = AtmosBC()).
+ * [5] sources (1 Gravity, 2 BomexTendencies, 4 BomexSponge, 8 BomexGeostrophic), [6] nbc,
+ * [7..13] bc kinds (1 = AtmosBC(); 2 = the BOMEX surface: Impenetrable(DragLaw(u_star)),
+ * PrescribedEnergyFlux, PrescribedMoistureFlux).  dparam[32..49]: the BOMEX constants.
  * dparam[0] viscosity | C_smag | C_poincare, [2..9] R_d cp_d cv_d T_0 grav MSLP inv_Pr_turb
  * tolerance, [16..26] R_v cp_v cp_l cp_i LH_v0 LH_s0 T_triple T_freeze T_icenuc press_triple T_min.
  */
@@ -36,6 +38,9 @@ typedef struct {
     double visc, R_d, cp_d, cv_d, T_0, grav, MSLP, invPr, tol;
     double R_v, cp_v, cp_l, cp_i, LH_v0, LH_s0, T_triple, T_freeze, T_icenuc, p_triple, T_min;
     int ngt; /* turbulence entries of the gradient flux: 7 (S, N^2) or 10 (grad u, N^2) */
+    /* BOMEX (experiments/AtmosLES/bomex_model.jl:76-246, 352-470): surface fluxes and sources */
+    double u_star, e_flux, q_flux, f_cor, u_geo, u_slope, v_geo, z_sponge, a_max, gam, z_max;
+    double dqt_peak, zl_m, zh_m, dth_peak, zl_sub, zh_sub, w_sub;
 } moist_t;
 enum { OPHI = 3, OREF = 7, OTURB = 14, OMOIST = 15, NAUXM = 19 };
 
@@ -260,15 +265,74 @@ static void mo_flux2(const void *p_, double *F, const double *Q, const double *g
     for (int d = 0; d < 3; ++d) F[d + 15] = dq[d] * rho; /* TotalMoisture: MoistureDiffusion */
 }
 
+static inline double exner_of(const moist_t *m, const thermo_t *ts, double rho)
+{
+    return pow(air_pressure(ts, rho) / m->MSLP, ts->R_m / ts->cp_m);
+}
+/* sources in the order of the model's tuple: Gravity, BomexTendencies, BomexSponge,
+   BomexGeostrophic (bomex_model.jl:396-420); each prognostic variable sums its terms in it */
 static void mo_source(const void *p_, double *S, const double *Q, const double *gf, const double *aux,
                       double t, int dir)
 {
     const moist_t *m = (const moist_t *)p_;
-    (void)gf; (void)t; (void)dir;
+    (void)t; (void)dir;
     for (int q = 0; q < 6; ++q) S[q] = 0;
+    const double rho = Q[0];
+    double k[3];
+    for (int d = 0; d < 3; ++d) k[d] = aux[OPHI + 1 + d] / m->grav;
+    const double z = aux[OPHI] / m->grav; /* altitude */
+    int first = 1;
     if (m->src & 1) { /* Gravity */
-        const double r = m->subtract ? Q[0] - aux[OREF] : Q[0];
+        const double r = m->subtract ? rho - aux[OREF] : rho;
         for (int d = 0; d < 3; ++d) S[1 + d] = -r * aux[OPHI + 1 + d];
+        first = 0;
+    }
+    if (m->src & 2) { /* BomexTendencies: moisture, radiative cooling, subsidence (:141-246) */
+        double rdqt, rdth, w_s = -0.0;
+        const double lm = (z - m->zl_m) / (m->zh_m - m->zl_m);
+        if (z <= m->zl_m) rdqt = rho * m->dqt_peak;
+        else if (z <= m->zh_m) rdqt = rho * (m->dqt_peak - m->dqt_peak * lm);
+        else rdqt = -0.0;
+        const double lt = (z - m->zl_sub) / (m->z_max - m->zl_sub);
+        if (z <= m->zl_sub) rdth = rho * m->dth_peak;
+        else if (z <= m->z_max) rdth = rho * (m->dth_peak - m->dth_peak * lt);
+        else rdth = -0.0;
+        const double ls = (z - m->zl_sub) / (m->zh_sub - m->zl_sub);
+        if (z <= m->zl_sub) w_s = -0.0 + z * (m->w_sub) / (m->zl_sub);
+        else if (z <= m->zh_sub) w_s = m->w_sub - (m->w_sub) * ls;
+        const double *gq = gf + 3 + m->ngt;
+        const double kq = k[0] * gq[0] + k[1] * gq[1] + k[2] * gq[2];
+        const double kh = k[0] * gf[0] + k[1] * gf[1] + k[2] * gf[2];
+        S[0] = rdqt - rho * w_s * kq;
+        S[5] = rdqt - rho * w_s * kq;
+        thermo_t ts;
+        thermo_state(m, Q, aux, &ts);
+        const double term1 = ts.cv_m * rdth * exner_of(m, &ts, rho) + e_int_v0(m) * rdqt;
+        const double term2 = rho * w_s * kh;
+        S[4] = term1 - term2;
+    }
+    const double ug[3] = {m->u_geo + m->u_slope * z, m->v_geo, 0.0};
+    if (m->src & 4) { /* BomexSponge (:106-133) */
+        double v[3] = {0, 0, 0};
+        if (m->z_sponge <= z) {
+            const double r = (z - m->z_sponge) / (m->z_max - m->z_sponge);
+            const double sp = sin(M_PI * (r / 2));
+            const double beta = m->a_max * (m->gam == 2 ? sp * sp : pow(sp, m->gam));
+            for (int d = 0; d < 3; ++d) v[d] = -beta * (Q[1 + d] - rho * ug[d]);
+        }
+        for (int d = 0; d < 3; ++d) S[1 + d] = first ? v[d] : S[1 + d] + v[d];
+        first = 0;
+    }
+    if (m->src & 8) { /* BomexGeostrophic: -(f k) x (rho u - rho u_geo) (:79-104) */
+        double a[3], b[3];
+        for (int d = 0; d < 3; ++d) {
+            a[d] = m->f_cor * k[d];
+            b[d] = Q[1 + d] - rho * ug[d];
+        }
+        const double c[3] = {-(a[1] * b[2] - a[2] * b[1]), -(a[2] * b[0] - a[0] * b[2]),
+                             -(a[0] * b[1] - a[1] * b[0])};
+        for (int d = 0; d < 3; ++d) S[1 + d] = first ? c[d] : S[1 + d] + c[d];
+        first = 0;
     }
 }
 
@@ -343,20 +407,44 @@ static void mo_bstate(const void *p_, int kind, int bctag, double *QP, double *a
 {
     const moist_t *m = (const moist_t *)p_;
     (void)auxM; (void)t; (void)Q1; (void)aux1;
-    if (m->bc[bctag - 1] == 1) { /* Impenetrable(FreeSlip), Insulating, Impermeable */
+    const int bc = m->bc[bctag - 1];
+    if (bc == 1 || bc == 2) { /* Impenetrable: FreeSlip, and DragLaw reflects the same way
+                                 (bc_momentum.jl:21-40, 88-102) */
         const double dn = QM[1] * n[0] + QM[2] * n[1] + QM[3] * n[2];
         const double f = kind == ORC_BS_FIRST ? 2 * dn : dn;
         for (int d = 0; d < 3; ++d) QP[1 + d] -= f * n[d];
     }
     moist_update(m, QP, auxP);
 }
+/* normal_boundary_flux_second_order! of AtmosBC (boundaryconditions.jl:101-140): the default
+   conditions add nothing; the BOMEX surface adds the drag-law stress (bc_momentum.jl:103-118),
+   the prescribed energy flux (bc_energy.jl:87-99) and the prescribed moisture flux
+   (bc_moisture.jl:38-52).  They are normal fluxes X; the caller forms F . n, so F = X n. */
 static void mo_bflux2(const void *p_, int bctag, double *F, double *QP, double *gfP, double *hypP,
                       double *auxP, const double *n, const double *QM, const double *gfM,
                       const double *hypM, const double *auxM, double t, const double *Q1,
                       const double *gf1, const double *aux1)
 {
-    (void)p_; (void)bctag; (void)F; (void)QP; (void)gfP; (void)hypP; (void)auxP; (void)n; (void)QM;
-    (void)gfM; (void)hypM; (void)auxM; (void)t; (void)Q1; (void)gf1; (void)aux1;
+    const moist_t *m = (const moist_t *)p_;
+    (void)QP; (void)gfP; (void)hypP; (void)auxP; (void)gfM; (void)hypM; (void)auxM; (void)t; (void)gf1;
+    (void)aux1;
+    if (m->bc[bctag - 1] != 2) return;
+    double X[6] = {0, 0, 0, 0, 0, 0};
+    /* momentum: tau_n = C |u_tan| u_tan with C = (u_star / |u_tan|)^2, u of the first interior node */
+    double u1[3], ut[3];
+    for (int d = 0; d < 3; ++d) u1[d] = Q1[1 + d] / Q1[0];
+    const double un = u1[0] * n[0] + u1[1] * n[1] + u1[2] * n[2];
+    for (int d = 0; d < 3; ++d) ut[d] = u1[d] - un * n[d];
+    const double nut = sqrt(ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2]);
+    const double Cd = (m->u_star / nut) * (m->u_star / nut);
+    for (int d = 0; d < 3; ++d) X[1 + d] += QM[0] * (Cd * nut * ut[d]);
+    X[4] -= m->e_flux; /* inward energy flux LHF + SHF */
+    const double nrd = -m->q_flux;
+    X[0] += nrd;
+    for (int d = 0; d < 3; ++d) X[1 + d] += nrd / QM[0] * QM[1 + d];
+    X[5] += nrd;
+    for (int s = 0; s < 6; ++s)
+        for (int d = 0; d < 3; ++d) F[d + 3 * s] += X[s] * n[d];
 }
 static void mo_bdiv(const void *p_, int bctag, double *gradP, double *auxP, const double *n,
                     const double *gradM, const double *auxM, double t)
@@ -399,6 +487,10 @@ orc_physics *orc_moist_new(const int *ip, const double *dp, int nf_first)
     m->LH_s0 = dp[21]; m->T_triple = dp[22]; m->T_freeze = dp[23]; m->T_icenuc = dp[24];
     m->p_triple = dp[25]; m->T_min = dp[26];
     m->ngt = m->closure == 2 ? 10 : 7;
+    m->u_star = dp[32]; m->e_flux = dp[33]; m->q_flux = dp[34]; m->f_cor = dp[35]; m->u_geo = dp[36];
+    m->u_slope = dp[37]; m->v_geo = dp[38]; m->z_sponge = dp[39]; m->a_max = dp[40]; m->gam = dp[41];
+    m->z_max = dp[42]; m->dqt_peak = dp[43]; m->zl_m = dp[44]; m->zh_m = dp[45]; m->dth_peak = dp[46];
+    m->zl_sub = dp[47]; m->zh_sub = dp[48]; m->w_sub = dp[49];
     ph->ns = 6;
     ph->naux = NAUXM;
     ph->ngrad = 6;

@@ -384,3 +384,17 @@ def density_current_setup(Ne=(100, 2, 50), N=4):
                              closure=MO.CLOSURE_ANISO_MIN_DISS, coefficient=1.0,
                              boundary_conditions=(A.BC_ATMOS_DEFAULT,), param_set=ps)
     return law, grid, 0.01, 10
+
+
+def bomex_setup(nx=4, ny=4, nz=8, N=4, rank=0, size=1, zmax=3000.0, L=None):
+    """experiments/AtmosLES/bomex_les.jl through AtmosLESConfiguration: periodic in x and y,
+    boundary (1, 2) in z, 3 km deep; the reference uses 6.4 km x 6.4 km at (100, 100, 40) m
+    resolution, the tests a reduced box with the same element aspect."""
+    MO = cm.moist
+    L = L if L is not None else 400.0 * nx
+    rng = [np.linspace(0.0, L, nx + 1), np.linspace(0.0, L * ny / nx, ny + 1),
+           np.linspace(0.0, zmax, nz + 1)]
+    topl = M.StackedBrickTopology(rng, periodicity=(True, True, False),
+                                  boundary=((0, 0), (0, 0), (1, 2)), rank=rank, size=size)
+    grid = M.DiscontinuousSpectralElementGrid(topl, N)
+    return MO.bomex_model(zmax), grid

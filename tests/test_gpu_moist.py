@@ -120,3 +120,36 @@ def test_density_current_reference_number_on_the_device(cm, torch):
     assert abs(ratio - ref) <= 1.5e-8 * ref
     assert abs((1 - ratio) - (1 - ref)) <= 2e-4 * (1 - ref)
     dg.close()
+
+
+@pytest.mark.parametrize("N", [4, 6])
+def test_bomex_tendency_and_steps_match_oracle(cm, oracle, torch, N):
+    """BOMEX sources (tendencies, sponge, geostrophic forcing) and surface conditions (drag law,
+    prescribed energy and moisture fluxes) on the device against the oracle."""
+    from helpers import bomex_setup
+    law, grid = bomex_setup(nx=3, ny=2, nz=6 if N == 4 else 4, N=N)
+    law.maxiter, law.tolerance = 40, 1e-11          # converged adjustment, see _cloudy
+    odg = oracle.OracleDGModel(law, grid)
+    dg = cm.dgmodel.DGModel(law, grid)
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    rng = np.random.default_rng(N)
+    Q0[:, 1:4] += Q0[:, 0:1] * 0.5 * rng.standard_normal(Q0[:, 1:4].shape)
+    Q0[:, 5] *= 1 + 0.05 * rng.random(Q0[:, 5].shape)          # some cloud
+    To = np.zeros_like(Q0)
+    odg(To, Q0.copy(), 0.0, 1.0, 0.0)
+    Tg = _gpu(torch, np.zeros_like(Q0))
+    dg(Tg, _gpu(torch, Q0), 0.0, 1.0, 0.0)
+    Tn = Tg.cpu().numpy()
+    assert odg.state_auxiliary[:, 17].max() > 1e-5
+    for s in range(6):
+        assert rel_linf(Tn[:, s], To[:, s]) < 1e-11, s
+    Qo, dQo = Q0.copy(), np.zeros_like(Q0)
+    for i in range(2):
+        oracle.lsrk54_step(odg, Qo, dQo, i * 0.05, 0.05)
+    Q = _gpu(torch, Q0)
+    dQ = torch.zeros_like(Q)
+    dg.lsrk_run(Q, dQ, 0.0, 0.05, 2, oracle.RKA, oracle.RKB, oracle.RKC)
+    dg.synchronize()
+    for s in range(6):
+        assert rel_linf(Q.cpu().numpy()[:, s], Qo[:, s]) < 1e-11, s
+    dg.close()
