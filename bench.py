@@ -102,13 +102,34 @@ def build_workload(cm, name, rank, size, ne, args):
                 "elements": nx * ny * nz, "nodes_per_element": 125, "states": law.ns,
                 "parallelism": "element partition (Hilbert, whole columns), %d rank(s)" % size}
         return law, grid, (0, 0), 0.1, desc
+    if name == "bomex":
+        # BASELINE.json configs[3]: BOMEX moist LES at N = 6, about 65 k elements on 8 GPUs
+        # (experiments/AtmosLES/bomex_les.jl + bomex_model.jl: 6.4 km x 6.4 km x 3 km, periodic
+        # in x and y, EquilMoist, SmagorinskyLilly(0.23), BOMEX sources and surface fluxes);
+        # per GPU: ne x ne x 2 ne elements of (200 m, 200 m, 3000 / (2 ne) m), weak scaling in y.
+        MO = cm.moist
+        ne = args.ne if args.ne != 32 else 16
+        nx, ny, nz = ne, ne * size, 2 * ne
+        rng = [np.linspace(0.0, 200.0 * nx, nx + 1), np.linspace(0.0, 200.0 * ny, ny + 1),
+               np.linspace(0.0, 3000.0, nz + 1)]
+        topl = M.StackedBrickTopology(rng, periodicity=(True, True, False),
+                                      boundary=((0, 0), (0, 0), (1, 2)), rank=rank, size=size)
+        grid = M.DiscontinuousSpectralElementGrid(topl, 6)
+        law = MO.bomex_model(3000.0)
+        desc = {"workload": "BOMEX moist LES (BASELINE configs[3]), stacked brick %dx%dx%d elements, "
+                            "N=6, EquilMoist (saturation adjustment in every flux evaluation, as "
+                            "in the reference snapshot), SmagorinskyLilly, BOMEX sources and "
+                            "surface fluxes, LSRK54 explicit, Rusanov, fp64" % (nx, ny, nz),
+                "elements": nx * ny * nz, "nodes_per_element": 343, "states": law.ns,
+                "parallelism": "element partition (Hilbert, whole columns), %d rank(s)" % size}
+        return law, grid, (0, 0), 0.004, desc
     raise SystemExit("unknown workload %s" % name)
 
 
-def algorithmic_bytes_per_node(law, kernel):
+def algorithmic_bytes_per_node(law, kernel, Nq=5):
     """SURVEY.md section 8(d): every distinct array element a pass needs moves once;
-    face tables add F = (5*8 + 2*8) * 6 * Nfp / Np = 67 B per node at N = 4."""
-    b, F = 8, 67
+    face tables add F = (5*8 + 2*8) * 6 * Nfp / Np = 336 / Nq B per node (67 at N = 4)."""
+    b, F = 8, int(round(336 / Nq))
     ns, naux, ngf, ngl, nhyp = law.ns, law.naux, law.ngradflux, law.ngradlap, law.nhyper
     if kernel == "GRADIENTS":
         return b * (ns + naux + 9 + ngf + 3 * ngl) + F
@@ -150,7 +171,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="heldsuarez", choices=["heldsuarez", "advdiff-brick", "risingbubble"])
+    ap.add_argument("--workload", default="heldsuarez", choices=["heldsuarez", "advdiff-brick", "risingbubble", "bomex"])
     ap.add_argument("--ne", type=int, default=32, help="advdiff-brick: elements per side per rank")
     ap.add_argument("--nhorz", type=int, default=0, help="heldsuarez: elements per cube edge")
     ap.add_argument("--nvert", type=int, default=8, help="heldsuarez: vertical elements")
@@ -266,7 +287,7 @@ def main():
                   key=lambda k: kern[k][0] * kern[k][1])
         avg_ms, nl = kern[dom]
         elems_per_launch = grid.nreal * 5 * args.steps / nl   # interior/exterior launches split
-        bytes_per_launch = algorithmic_bytes_per_node(law, dom) * grid.Np * elems_per_launch
+        bytes_per_launch = algorithmic_bytes_per_node(law, dom, grid.N[0] + 1) * grid.Np * elems_per_launch
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         # HBM-side traffic of the dominant kernel from the committed rocprofv3 --pmc passes of
         # this same command (scripts/pmc_any.sh; FETCH_SIZE and WRITE_SIZE in separate passes, KB
@@ -295,7 +316,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "algorithmic_bytes_per_node": algorithmic_bytes_per_node(law, dom),
+                         "algorithmic_bytes_per_node": algorithmic_bytes_per_node(law, dom, grid.N[0] + 1),
                          "avg_launch_ms": avg_ms,
                          "timing": "HIP events on the launch stream, second pass of the same "
                                    "%d steps (%.3f ms/step with events)" % (

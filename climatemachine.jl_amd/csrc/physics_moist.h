@@ -145,13 +145,15 @@ struct MoistAtmos {
         ql = lam * qc;
         qi = (1 - lam) * qc;
     }
+    // unsat is set when the all-vapour temperature is below saturation: no condensate then
     __device__ static double saturation_adjustment(const Params &m, double e_int, double rho,
-                                                   double qt)
+                                                   double qt, bool &unsat)
     {
         double T = m.T_0 + (e_int - (qt - 0.0) * e_int_v0(m) + 0.0 * (e_int_v0(m) + e_int_i0(m))) /
                                cv_mix(m, qt, 0.0, 0.0);
         if (T < m.T_min) T = m.T_min;
-        if (qt <= q_vap_saturation(m, T, rho) && T > m.T_min) return T;
+        unsat = qt <= q_vap_saturation(m, T, rho) && T > m.T_min;
+        if (unsat) return T;
         for (int it = 0; it < m.maxiter; ++it) {  // Newton on e_int_sat(T) - e_int
             double ql, qi;
             phase_partition_equil(m, T, rho, qt, ql, qi);
@@ -187,8 +189,14 @@ struct MoistAtmos {
     {
         const double e_int = internal_energy(Q, aux);
         ts.q_tot = Q[5] / Q[0];
-        ts.T = saturation_adjustment(m, e_int, Q[0], ts.q_tot);
-        phase_partition_equil(m, ts.T, Q[0], ts.q_tot, ts.q_liq, ts.q_ice);
+        bool unsat;
+        ts.T = saturation_adjustment(m, e_int, Q[0], ts.q_tot, unsat);
+        if (unsat) {  // q_c = max(q_tot - q_vap_sat, 0) = 0: the partition needs no second look
+            ts.q_liq = 0.0;
+            ts.q_ice = 0.0;
+        } else {
+            phase_partition_equil(m, ts.T, Q[0], ts.q_tot, ts.q_liq, ts.q_ice);
+        }
         const double eps = m.R_v / m.R_d;
         ts.R_m = m.R_d * (1 + (eps - 1) * ts.q_tot - eps * (ts.q_liq + ts.q_ice));
         ts.cv_m = cv_mix(m, ts.q_tot, ts.q_liq, ts.q_ice);

@@ -100,11 +100,12 @@ static inline void phase_partition_equil(const moist_t *m, double T, double rho,
     *ql = lam * qc;
     *qi = (1 - lam) * qc;
 }
-static double saturation_adjustment(const moist_t *m, double e_int, double rho, double qt)
+static double saturation_adjustment(const moist_t *m, double e_int, double rho, double qt, int *unsat)
 {
     double T = air_temperature(m, e_int, qt, 0.0, 0.0); /* all vapour */
     if (T < m->T_min) T = m->T_min;
-    if (qt <= q_vap_saturation(m, T, rho) && T > m->T_min) return T;
+    *unsat = qt <= q_vap_saturation(m, T, rho) && T > m->T_min;
+    if (*unsat) return T;
     for (int it = 0; it < m->maxiter; ++it) { /* Newton on e_int_sat(T) - e_int */
         double ql, qi;
         phase_partition_equil(m, T, rho, qt, &ql, &qi);
@@ -141,8 +142,14 @@ static void thermo_state(const moist_t *m, const double *Q, const double *aux, t
 {
     ts->e_int = internal_energy(Q, aux);
     ts->q_tot = Q[5] / Q[0];
-    ts->T = saturation_adjustment(m, ts->e_int, Q[0], ts->q_tot);
-    phase_partition_equil(m, ts->T, Q[0], ts->q_tot, &ts->q_liq, &ts->q_ice);
+    int unsat;
+    ts->T = saturation_adjustment(m, ts->e_int, Q[0], ts->q_tot, &unsat);
+    if (unsat) { /* q_c = max(q_tot - q_vap_sat, 0) = 0 */
+        ts->q_liq = 0.0;
+        ts->q_ice = 0.0;
+    } else {
+        phase_partition_equil(m, ts->T, Q[0], ts->q_tot, &ts->q_liq, &ts->q_ice);
+    }
     ts->R_m = gas_constant_air(m, ts->q_tot, ts->q_liq, ts->q_ice);
     ts->cv_m = cv_mix(m, ts->q_tot, ts->q_liq, ts->q_ice);
     ts->cp_m = cp_mix(m, ts->q_tot, ts->q_liq, ts->q_ice);
@@ -467,7 +474,8 @@ double orc_moist_saturation_adjustment(const orc_physics *ph, double e_int, doub
                                        double *q_liq, double *q_ice, double *e_int_back)
 {
     const moist_t *m = (const moist_t *)ph->p;
-    const double T = saturation_adjustment(m, e_int, rho, q_tot);
+    int unsat;
+    const double T = saturation_adjustment(m, e_int, rho, q_tot, &unsat);
     phase_partition_equil(m, T, rho, q_tot, q_liq, q_ice);
     *e_int_back = internal_energy_T(m, T, q_tot, *q_liq, *q_ice);
     return T;
