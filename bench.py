@@ -108,7 +108,7 @@ def build_workload(cm, name, rank, size, ne, args):
         # in x and y, EquilMoist, SmagorinskyLilly(0.23), BOMEX sources and surface fluxes);
         # per GPU: ne x ne x 2 ne elements of (200 m, 200 m, 3000 / (2 ne) m), weak scaling in y.
         MO = cm.moist
-        ne = args.ne if args.ne != 32 else 16
+        ne = args.bomex_ne
         nx, ny, nz = ne, ne * size, 2 * ne
         rng = [np.linspace(0.0, 200.0 * nx, nx + 1), np.linspace(0.0, 200.0 * ny, ny + 1),
                np.linspace(0.0, 3000.0, nz + 1)]
@@ -173,6 +173,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="heldsuarez", choices=["heldsuarez", "advdiff-brick", "risingbubble", "bomex"])
     ap.add_argument("--ne", type=int, default=32, help="advdiff-brick: elements per side per rank")
+    ap.add_argument("--bomex-ne", type=int, default=16,
+                    help="bomex: ne x ne x 2 ne elements per rank (32: the 65 536 elements of configs[3])")
     ap.add_argument("--nhorz", type=int, default=0, help="heldsuarez: elements per cube edge")
     ap.add_argument("--nvert", type=int, default=8, help="heldsuarez: vertical elements")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline")

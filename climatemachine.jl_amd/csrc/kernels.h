@@ -13,6 +13,8 @@
 // src/Numerics/DGMethods/DGModel_kernels.jl; the accumulation order of the reference
 // is kept term by term (see DESIGN.md "summation order").
 #pragma once
+#include <type_traits>
+
 #include "cmdg_common.h"
 
 // minimum waves per SIMD requested from the register allocator (tuning knobs)
@@ -115,6 +117,16 @@ __device__ __forceinline__ void face_setup(const GridDev &g, int64_t e, int f, i
     }
 }
 
+// A law may offer flux_first_order and wavespeed of one state in one call (both need the same
+// thermodynamic state; the moist law's costs a saturation adjustment): detected by the member
+// HAS_FLUX_WAVESPEED, absent from the other laws, whose code is unchanged.
+template <class P, class = void>
+struct has_flux_wavespeed : std::false_type {
+};
+template <class P>
+struct has_flux_wavespeed<P, std::void_t<decltype(P::HAS_FLUX_WAVESPEED)>> : std::true_type {
+};
+
 // numerical_flux_first_order!  NumericalFluxes.jl:223-285 (Rusanov) / :300-340 (central)
 template <class P>
 __device__ __forceinline__ void nf_first_order(const typename P::Params &prm, int nf,
@@ -125,19 +137,31 @@ __device__ __forceinline__ void nf_first_order(const typename P::Params &prm, in
 {
     constexpr int NS = P::NS;
     Vec<3 * NS> FM, FP;
+    Vec<NS> wM, wP;
     FM.negzero();
-    P::flux_first_order(prm, FM, QM, auxM, t, facedir);
     FP.negzero();
-    P::flux_first_order(prm, FP, QP, auxP, t, facedir);
+    if constexpr (has_flux_wavespeed<P>::value) {
+        if (nf == NF_RUSANOV) {
+            P::flux_wavespeed(prm, FM, wM, n, QM, auxM, t, facedir);
+            P::flux_wavespeed(prm, FP, wP, n, QP, auxP, t, facedir);
+        } else {
+            P::flux_first_order(prm, FM, QM, auxM, t, facedir);
+            P::flux_first_order(prm, FP, QP, auxP, t, facedir);
+        }
+    } else {
+        P::flux_first_order(prm, FM, QM, auxM, t, facedir);
+        P::flux_first_order(prm, FP, QP, auxP, t, facedir);
+    }
     const double nh0 = n[0] / 2, nh1 = n[1] / 2, nh2 = n[2] / 2;
 #pragma unroll
     for (int s = 0; s < NS; ++s)
         fluxn[s] += (FM[3 * s] + FP[3 * s]) * nh0 + (FM[3 * s + 1] + FP[3 * s + 1]) * nh1 +
                     (FM[3 * s + 2] + FP[3 * s + 2]) * nh2;
     if (nf == NF_RUSANOV) {
-        Vec<NS> wM, wP;
-        P::wavespeed(prm, wM, n, QM, auxM, t, facedir);
-        P::wavespeed(prm, wP, n, QP, auxP, t, facedir);
+        if constexpr (!has_flux_wavespeed<P>::value) {
+            P::wavespeed(prm, wM, n, QM, auxM, t, facedir);
+            P::wavespeed(prm, wP, n, QP, auxP, t, facedir);
+        }
         Vec<NS> pen;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {

@@ -39,10 +39,13 @@ struct MoistAtmos {
     static constexpr int OPHI = 3, OREF = 7, OTURB = 14, OMOIST = 15;
     static constexpr int NGT = CLOSURE == 2 ? 10 : 7;  // turbulence block of the gradient flux
     static constexpr int NS = 6, NAUX = 19, NGRAD = 6, NGF = 3 + NGT + 3, NGL = 0, NHYP = 0;
-    static constexpr bool HAS_UPDATE_AUX = true, FUSE_UPDATE_AUX = true, HAS_SOURCE = true;
+    // the nodal refresh (one saturation adjustment per node) runs as its own pass before the
+    // gradient kernel, as in the reference; the kernels then read temperature, theta_v and the
+    // condensate from the auxiliary state instead of repeating the adjustment where the
+    // reference reads them too (gradient argument / flux) or where the values are the same by
+    // construction (source)
+    static constexpr bool HAS_UPDATE_AUX = true, FUSE_UPDATE_AUX = false, HAS_SOURCE = true;
     static constexpr bool HAS_COURANT = false, HAS_PENALTY = false;
-    // entries the nodal refresh rewrites; read back by no kernel of the same evaluation
-    // (theta_v of the gradient argument is recomputed, see gradient_argument)
     static constexpr int NUPD = 4;
     __host__ __device__ static constexpr int upd_aux(int i) { return OMOIST + i; }
     static constexpr int NDER = 0;
@@ -197,6 +200,10 @@ struct MoistAtmos {
         } else {
             phase_partition_equil(m, ts.T, Q[0], ts.q_tot, ts.q_liq, ts.q_ice);
         }
+        mixture(m, ts);
+    }
+    __device__ static void mixture(const Params &m, Thermo &ts)
+    {
         const double eps = m.R_v / m.R_d;
         ts.R_m = m.R_d * (1 + (eps - 1) * ts.q_tot - eps * (ts.q_liq + ts.q_ice));
         ts.cv_m = cv_mix(m, ts.q_tot, ts.q_liq, ts.q_ice);
@@ -226,6 +233,22 @@ struct MoistAtmos {
     {
         Thermo ts;
         thermo_state(m, Q, aux, ts);
+        flux_first_order_ts(m, F, Q, aux, ts);
+    }
+    // flux_first_order and wavespeed of one state from one thermodynamic state (the Rusanov flux
+    // asks for both, kernels.h nf_first_order); same values as the two separate calls
+    static constexpr bool HAS_FLUX_WAVESPEED = true;
+    __device__ static void flux_wavespeed(const Params &m, double *F, double *ws, const double *n,
+                                          const double *Q, const double *aux, double, int)
+    {
+        Thermo ts;
+        thermo_state(m, Q, aux, ts);
+        flux_first_order_ts(m, F, Q, aux, ts);
+        wavespeed_ts(ws, n, Q, ts);
+    }
+    __device__ static void flux_first_order_ts(const Params &m, double *F, const double *Q,
+                                               const double *aux, const Thermo &ts)
+    {
         const double rho = Q[0];
         const double p = air_pressure(ts, rho);
         double u[3];
@@ -383,8 +406,13 @@ struct MoistAtmos {
             const double kh = k[0] * gf[0] + k[1] * gf[1] + k[2] * gf[2];
             S[0] = rdqt - rho * w_s * kq;
             S[5] = rdqt - rho * w_s * kq;
+            // the thermodynamic state of this node as the nodal refresh left it
             Thermo ts;
-            thermo_state(m, Q, aux, ts);
+            ts.T = aux[OMOIST];
+            ts.q_tot = Q[5] / Q[0];
+            ts.q_liq = aux[OMOIST + 2];
+            ts.q_ice = aux[OMOIST + 3];
+            mixture(m, ts);
             const double exner = pow(air_pressure(ts, rho) / m.MSLP, ts.R_m / ts.cp_m);
             const double term1 = ts.cv_m * rdth * exner + e_int_v0(m) * rdqt;
             const double term2 = rho * w_s * kh;
@@ -428,17 +456,13 @@ struct MoistAtmos {
         for (int d = 0; d < 3; ++d) G[d] = rhoinv * Q[1 + d];
         const double e_tot = Q[4] * (1 / Q[0]);
         G[3] = e_tot + ts.R_m * ts.T;
-        // transform.turbulence.theta_v = aux.moisture.theta_v: the nodal refresh of this same
-        // (Q, aux), evaluated here so that the fused refresh of neighbours is never read
-        G[4] = virtual_pottemp(m, ts, Q[0]);
+        G[4] = aux[OMOIST + 1];  // transform.turbulence.theta_v = aux.moisture.theta_v
         G[5] = Q[5] * rhoinv;
     }
     __device__ static void gradient_flux(const Params &m, double *gf, const double *g,
                                          const double *Q, const double *aux, double)
     {
-        Thermo ts;
-        thermo_state(m, Q, aux, ts);
-        const double th = virtual_pottemp(m, ts, Q[0]);
+        const double th = aux[OMOIST + 1];
 #pragma unroll
         for (int d = 0; d < 3; ++d) gf[d] = g[d + 9];
         double *T = gf + 3;
@@ -467,6 +491,11 @@ struct MoistAtmos {
     {
         Thermo ts;
         thermo_state(m, Q, aux, ts);
+        wavespeed_ts(ws, n, Q, ts);
+    }
+    __device__ static void wavespeed_ts(double *ws, const double *n, const double *Q,
+                                        const Thermo &ts)
+    {
         const double rhoinv = 1 / Q[0];
         const double uN =
             fabs(n[0] * (rhoinv * Q[1]) + n[1] * (rhoinv * Q[2]) + n[2] * (rhoinv * Q[3]));

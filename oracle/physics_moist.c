@@ -312,8 +312,15 @@ static void mo_source(const void *p_, double *S, const double *Q, const double *
         const double kh = k[0] * gf[0] + k[1] * gf[1] + k[2] * gf[2];
         S[0] = rdqt - rho * w_s * kq;
         S[5] = rdqt - rho * w_s * kq;
+        /* precomputed.ts: the state the nodal refresh of this evaluation left in aux */
         thermo_t ts;
-        thermo_state(m, Q, aux, &ts);
+        ts.T = aux[OMOIST];
+        ts.q_tot = Q[5] / Q[0];
+        ts.q_liq = aux[OMOIST + 2];
+        ts.q_ice = aux[OMOIST + 3];
+        ts.R_m = gas_constant_air(m, ts.q_tot, ts.q_liq, ts.q_ice);
+        ts.cv_m = cv_mix(m, ts.q_tot, ts.q_liq, ts.q_ice);
+        ts.cp_m = cp_mix(m, ts.q_tot, ts.q_liq, ts.q_ice);
         const double term1 = ts.cv_m * rdth * exner_of(m, &ts, rho) + e_int_v0(m) * rdqt;
         const double term2 = rho * w_s * kh;
         S[4] = term1 - term2;
