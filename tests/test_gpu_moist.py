@@ -153,3 +153,50 @@ def test_bomex_tendency_and_steps_match_oracle(cm, oracle, torch, N):
     for s in range(6):
         assert rel_linf(Q.cpu().numpy()[:, s], Qo[:, s]) < 1e-11, s
     dg.close()
+
+
+def test_bomex_local_multirank_matches_single_rank(cm, torch):
+    """three ranks of one process through the local transport: the nodal refresh of ghost
+    elements (after the exchange of Q) feeds theta_v and the condensate to the plus side."""
+    from helpers import bomex_setup
+    RKA, RKB, RKC = cm.odesolvers.LSRK144_COEFFICIENTS
+    law, grid = bomex_setup(nx=4, ny=3, nz=4)
+    law.maxiter, law.tolerance = 40, 1e-11
+    dg1 = cm.dgmodel.DGModel(law, grid)
+    Qh = law.init_state_prognostic(grid, dg1.state_auxiliary.cpu().numpy(), 0.0)
+    rng = np.random.default_rng(8)
+    Qh[:, 1:4] += Qh[:, 0:1] * 0.5 * rng.standard_normal(Qh[:, 1:4].shape)
+    Qh[:, 5] *= 1 + 0.05 * rng.random(Qh[:, 5].shape)
+    gl1 = grid.topology.globalelems
+    byglobal = {int(g): Qh[i] for i, g in enumerate(gl1[:grid.nreal])}
+    Q1 = _gpu(torch, Qh)
+    dQ1 = torch.zeros_like(Q1)
+    dg1.lsrk_run(Q1, dQ1, 0.0, 0.02, 2, RKA, RKB, RKC)
+    dg1.synchronize()
+    ref = {int(g): Q1[i].cpu().numpy() for i, g in enumerate(gl1[:grid.nreal])}
+    size = 3
+    dgs, Qs, grids = [], [], []
+    for r in range(size):
+        lawr, gridr = bomex_setup(nx=4, ny=3, nz=4, rank=r, size=size)
+        lawr.maxiter, lawr.tolerance = 40, 1e-11
+        d = cm.dgmodel.DGModel(lawr, gridr)
+        q = np.full((gridr.nelem, 6, gridr.Np), np.nan)
+        for i, g in enumerate(gridr.topology.globalelems[:gridr.nreal]):
+            q[i] = byglobal[int(g)]
+        dgs.append(d)
+        grids.append(gridr)
+        Qs.append(_gpu(torch, q))
+    cm.dgmodel.connect_local(dgs)
+    dQs = [torch.zeros_like(q) for q in Qs]
+    torch.cuda.synchronize()
+    cm.dgmodel.group_lsrk_run(dgs, Qs, dQs, 0.0, 0.02, 2, RKA, RKB, RKC)
+    for d in dgs:
+        d.synchronize()
+    for gr, q in zip(grids, Qs):
+        qn = q.cpu().numpy()
+        for i, g in enumerate(gr.topology.globalelems[:gr.nreal]):
+            for s in range(6):
+                sc = max(np.abs(ref[int(g)][s]).max(), 1e-6)
+                assert np.abs(qn[i, s] - ref[int(g)][s]).max() / sc < 1e-11, (s, i)
+    for d in dgs + [dg1]:
+        d.close()
