@@ -127,13 +127,23 @@ template <class P>
 struct has_flux_wavespeed<P, std::void_t<decltype(P::HAS_FLUX_WAVESPEED)>> : std::true_type {
 };
 
+// A law may also keep a few derived values per node (P::NCACHE doubles, P::node_cache) that its
+// first-order flux and wave speed are computed from: k_tendency then evaluates them once per
+// volume node and hands the staged copy to the minus side of the faces.
+template <class P, class = void>
+struct node_cache_size : std::integral_constant<int, 0> {
+};
+template <class P>
+struct node_cache_size<P, std::void_t<decltype(P::NCACHE)>> : std::integral_constant<int, P::NCACHE> {
+};
+
 // numerical_flux_first_order!  NumericalFluxes.jl:223-285 (Rusanov) / :300-340 (central)
 template <class P>
 __device__ __forceinline__ void nf_first_order(const typename P::Params &prm, int nf,
                                                Vec<P::NS> &fluxn, const double *n,
                                                const double *QM, const double *auxM,
                                                const double *QP, const double *auxP, double t,
-                                               int facedir)
+                                               int facedir, const double *cacheM = nullptr)
 {
     constexpr int NS = P::NS;
     Vec<3 * NS> FM, FP;
@@ -142,7 +152,14 @@ __device__ __forceinline__ void nf_first_order(const typename P::Params &prm, in
     FP.negzero();
     if constexpr (has_flux_wavespeed<P>::value) {
         if (nf == NF_RUSANOV) {
-            P::flux_wavespeed(prm, FM, wM, n, QM, auxM, t, facedir);
+            if constexpr (node_cache_size<P>::value > 0) {
+                if (cacheM)
+                    P::flux_wavespeed_cached(prm, FM, wM, n, QM, auxM, cacheM);
+                else
+                    P::flux_wavespeed(prm, FM, wM, n, QM, auxM, t, facedir);
+            } else {
+                P::flux_wavespeed(prm, FM, wM, n, QM, auxM, t, facedir);
+            }
             P::flux_wavespeed(prm, FP, wP, n, QP, auxP, t, facedir);
         } else {
             P::flux_first_order(prm, FM, QM, auxM, t, facedir);
@@ -208,7 +225,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
     constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGF = P::NGF,
                   NHYP = P::NHYP, NHG = 3 * P::NGL, NFA = P::NFAUX,
                   NSURF = SurfDims<NQ, NQV>::NSURF, NGFS = USE_GF ? NGF : 0,
-                  NMF = NS + NFA + NGFS + NHYP;
+                  NCA = node_cache_size<P>::value, NMF = NS + NFA + NGFS + NHYP + NCA;
     __shared__ double sD[NQ * NQ + (NQV == NQ ? 0 : NQV * NQV)];
     const double *const sDv = sD + (NQV == NQ ? 0 : NQ * NQ);  // vertical derivative matrix
     __shared__ double sF[3 * NS * Np];  // contravariant flux [d][s][ijk]; later the accumulator
@@ -267,7 +284,18 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
         }
         Vec<3 * NS> F, F2;
         F.negzero();
-        P::flux_first_order(a.prm, F, lQ, laux, a.t, a.model_dir);
+        if constexpr (NCA > 0) {
+            Vec<NCA> lc;
+            P::node_cache(a.prm, lc, lQ, laux);
+            P::flux_first_order_cached(a.prm, F, lQ, laux, lc);
+            if (sidx >= 0) {
+#pragma unroll
+                for (int s = 0; s < NCA; ++s)
+                    sM[(NS + NFA + NGFS + NHYP + s) * NSURF + sidx] = lc[s];
+            }
+        } else {
+            P::flux_first_order(a.prm, F, lQ, laux, a.t, a.model_dir);
+        }
         F2.negzero();
         P::flux_second_order(a.prm, F2, lQ, lgf, lhyp, laux, a.t);
 #pragma unroll
@@ -362,6 +390,9 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
             for (int s = 0; s < NAUX; ++s) auxM[s] = 0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) QM[s] = sM[s * NSURF + sidx];
+            Vec<NCA> cM;  // the law's per-node cache of the minus side (see node_cache_size)
+#pragma unroll
+            for (int s = 0; s < NCA; ++s) cM[s] = sM[(NS + NFA + NGFS + NHYP + s) * NSURF + sidx];
 #pragma unroll
             for (int s = 0; s < NFA; ++s) auxM[P::face_aux(s)] = sM[(NS + s) * NSURF + sidx];
 #pragma unroll
@@ -390,7 +421,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
             flux.negzero();
             if (fp.bctag == 0) {
                 nf_first_order<P>(a.prm, a.nf_first, flux, fp.n, QM, auxM, QPn, auxPn, a.t,
-                                  facedir);
+                                  facedir, NCA > 0 ? (const double *)cM : nullptr);
                 // CentralNumericalFluxSecondOrder  NumericalFluxes.jl:670-715
                 Vec<3 * NS> FM, FP;
                 FM.negzero();
@@ -424,7 +455,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
                 P::boundary_state(a.prm, BS_FIRST, fp.bctag, QPn, auxPn, fp.n, QM, auxM, a.t, Q1,
                                   aux1);
                 nf_first_order<P>(a.prm, a.nf_first, flux, fp.n, QM, auxM, QPn, auxPn, a.t,
-                                  facedir);
+                                  facedir, NCA > 0 ? (const double *)cM : nullptr);
                 // normal_boundary_flux_second_order!  NumericalFluxes.jl:872-918
                 Vec<3 * NS> FP;
                 FP.negzero();

@@ -246,6 +246,42 @@ struct MoistAtmos {
         flux_first_order_ts(m, F, Q, aux, ts);
         wavespeed_ts(ws, n, Q, ts);
     }
+    // per-node cache: temperature and condensate of the equilibrium state; the minus side of the
+    // faces reuses what the volume node computed (kernels.h node_cache_size)
+    static constexpr int NCACHE = 3;
+    __device__ static void node_cache(const Params &m, double *c, const double *Q, const double *aux)
+    {
+        Thermo ts;
+        thermo_state(m, Q, aux, ts);
+        c[0] = ts.T;
+        c[1] = ts.q_liq;
+        c[2] = ts.q_ice;
+    }
+    __device__ static void thermo_from_cache(const Params &m, const double *Q, const double *c,
+                                             Thermo &ts)
+    {
+        ts.T = c[0];
+        ts.q_tot = Q[5] / Q[0];
+        ts.q_liq = c[1];
+        ts.q_ice = c[2];
+        mixture(m, ts);
+    }
+    __device__ static void flux_first_order_cached(const Params &m, double *F, const double *Q,
+                                                   const double *aux, const double *c)
+    {
+        Thermo ts;
+        thermo_from_cache(m, Q, c, ts);
+        flux_first_order_ts(m, F, Q, aux, ts);
+    }
+    __device__ static void flux_wavespeed_cached(const Params &m, double *F, double *ws,
+                                                 const double *n, const double *Q,
+                                                 const double *aux, const double *c)
+    {
+        Thermo ts;
+        thermo_from_cache(m, Q, c, ts);
+        flux_first_order_ts(m, F, Q, aux, ts);
+        wavespeed_ts(ws, n, Q, ts);
+    }
     __device__ static void flux_first_order_ts(const Params &m, double *F, const double *Q,
                                                const double *aux, const Thermo &ts)
     {
