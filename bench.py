@@ -228,12 +228,17 @@ def main():
     solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
     step_filter = None
     if args.filter:
-        assert args.workload == "heldsuarez"
+        assert args.workload in ("heldsuarez", "bomex")
         F = cm.mesh.filters
-        step_filter = F.make_device_filter(dg, F.ExponentialFilter(grid, 0, 20),
-                                           F.AtmosFilterPerturbations(law))
+        if args.workload == "bomex":
+            # the experiment's every-step callback (bomex_les.jl:97-117): TMAR filter of q_tot
+            step_filter = F.make_device_filter(dg, F.TMARFilter(), F.FilterIndices(6))
+            desc = dict(desc, step_filter="TMARFilter on moisture.rho q_tot")
+        else:
+            step_filter = F.make_device_filter(dg, F.ExponentialFilter(grid, 0, 20),
+                                               F.AtmosFilterPerturbations(law))
+            desc = dict(desc, step_filter="ExponentialFilter(grid, 0, 20) on AtmosFilterPerturbations")
         dg.set_filters(step_filter=step_filter)
-        desc = dict(desc, step_filter="ExponentialFilter(grid, 0, 20) on AtmosFilterPerturbations")
 
     def sync_all():
         dg.synchronize()
