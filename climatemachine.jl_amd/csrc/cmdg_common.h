@@ -35,14 +35,6 @@ struct KDims {
     static constexpr int Nfp = Nfph > Nfpv ? Nfph : Nfpv;
     static constexpr int NFT = 4 * Nfph + 2 * Nfpv;  // face-node tasks per element
     static constexpr int NT = (((Np > NFT ? Np : NFT) + 63) / 64) * 64;
-    // k_tendency may run its face tasks in passes of fewer threads (two waves instead of three
-    // at N = 4: the third wave only ever carries 22 face tasks); build option, see DESIGN.md
-#ifdef CMDG_TEND_NT128
-    static constexpr int NTT = (NQ == 5 && NQV == 5) ? 128 : NT;
-#else
-    static constexpr int NTT = NT;
-#endif
-    static constexpr int NPASS = (NFT + NTT - 1) / NTT;
     __device__ __forceinline__ static void face_task(int t, int &f, int &n)
     {
         if constexpr (NQ == NQV) {

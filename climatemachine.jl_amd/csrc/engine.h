@@ -221,7 +221,7 @@ struct EngineT : EngineBase {
 #else
         const bool gfl = P::needs_gradflux(prm);
 #endif
-        const dim3 grid((unsigned)n), block(KDims<NQ_, NQV_>::NTT);
+        const dim3 grid((unsigned)n), block(KDims<NQ_, NQV_>::NT);
         const PassArgs<P> args = make_args(c, elems, n, direction);
         if (c.lsrk) {
             if (gfl)

@@ -219,19 +219,13 @@ struct SurfDims {
 // Tendency pass: volume_tendency! (:64-548) + dgsem_interface_tendency! (:588-901),
 // optionally fused with the LSRK update! (LowStorageRungeKuttaMethod.jl:146-158).
 template <class P, int NQ, int NQV, bool LSRK, bool USE_GF>
-__global__ void __launch_bounds__((KDims<NQ, NQV>::NTT), CMDG_TEND_MINW) k_tendency(const PassArgs<P> a)
+__global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tendency(const PassArgs<P> a)
 {
     using KD = KDims<NQ, NQV>;
     constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGF = P::NGF,
                   NHYP = P::NHYP, NHG = 3 * P::NGL, NFA = P::NFAUX,
                   NSURF = SurfDims<NQ, NQV>::NSURF, NGFS = USE_GF ? NGF : 0,
-                  NCA = node_cache_size<P>::value,
-#ifdef CMDG_TEND_RELOAD_HYP  // experiment: minus-side hyperdiffusive state re-read, not staged
-                  NHS = 0,
-#else
-                  NHS = NHYP,
-#endif
-                  NMF = NS + NFA + NGFS + NHS + NCA;
+                  NCA = node_cache_size<P>::value, NMF = NS + NFA + NGFS + NHYP + NCA;
     __shared__ double sD[NQ * NQ + (NQV == NQ ? 0 : NQV * NQV)];
     const double *const sDv = sD + (NQV == NQ ? 0 : NQ * NQ);  // vertical derivative matrix
     __shared__ double sF[3 * NS * Np];  // contravariant flux [d][s][ijk]; later the accumulator
@@ -286,7 +280,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NTT), CMDG_TEND_MINW) k_tende
                 for (int s = 0; s < NGF; ++s) sM[(NS + NFA + s) * NSURF + sidx] = lgf[s];
             }
 #pragma unroll
-            for (int s = 0; s < NHS; ++s) sM[(NS + NFA + NGFS + s) * NSURF + sidx] = lhyp[s];
+            for (int s = 0; s < NHYP; ++s) sM[(NS + NFA + NGFS + s) * NSURF + sidx] = lhyp[s];
         }
         Vec<3 * NS> F, F2;
         F.negzero();
@@ -297,7 +291,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NTT), CMDG_TEND_MINW) k_tende
             if (sidx >= 0) {
 #pragma unroll
                 for (int s = 0; s < NCA; ++s)
-                    sM[(NS + NFA + NGFS + NHS + s) * NSURF + sidx] = lc[s];
+                    sM[(NS + NFA + NGFS + NHYP + s) * NSURF + sidx] = lc[s];
             }
         } else {
             P::flux_first_order(a.prm, F, lQ, laux, a.t, a.model_dir);
@@ -374,27 +368,15 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NTT), CMDG_TEND_MINW) k_tende
         for (int s = 0; s < NS; ++s) sT[s * Np + tid] = Tv[s];
     }
     // ---- faces: dgsem_interface_tendency! ------------------------------------------
-    // (KD::NPASS passes of KD::NTT tasks; one pass unless built with CMDG_TEND_NT128.  Faces are
-    // numbered along the tasks, so within and across passes every node still receives its
-    // face contributions in the order 1 ... 6.)
-#pragma unroll
-    for (int pass = 0; pass < KD::NPASS; ++pass) {
     Vec<NS> lift;
     int vidM = 0, fpair = -1;
-    const int task = tid + pass * KD::NTT;
-    if (pass > 0) {  // the tables of the first pass were fetched at kernel start
-        int f_f = 0, f_n = 0;
-        if (task < KD::NFT) KD::face_task(task, f_f, f_n);
-        face_on = task < KD::NFT && (f_f < 4 ? hz : vt);
-        if (face_on) face_index<NQ, NQV>(a.g, e, f_f, f_n, f_idM, f_idP, f_bctag);
-    }
 #ifdef CMDG_DBG_NOFACE
     if (false) {
 #else
-    if (task < KD::NFT) {
+    if (tid < KD::NFT) {
 #endif
         int f, n;  // recomputed: cheaper than two registers live across the volume phases
-        KD::face_task(task, f, n);
+        KD::face_task(tid, f, n);
         if (face_on) {
             const int facedir = f < 4 ? DIR_HORIZONTAL : DIR_VERTICAL;
             FacePt fp;
@@ -410,7 +392,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NTT), CMDG_TEND_MINW) k_tende
             for (int s = 0; s < NS; ++s) QM[s] = sM[s * NSURF + sidx];
             Vec<NCA> cM;  // the law's per-node cache of the minus side (see node_cache_size)
 #pragma unroll
-            for (int s = 0; s < NCA; ++s) cM[s] = sM[(NS + NFA + NGFS + NHS + s) * NSURF + sidx];
+            for (int s = 0; s < NCA; ++s) cM[s] = sM[(NS + NFA + NGFS + NHYP + s) * NSURF + sidx];
 #pragma unroll
             for (int s = 0; s < NFA; ++s) auxM[P::face_aux(s)] = sM[(NS + s) * NSURF + sidx];
 #pragma unroll
@@ -421,9 +403,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NTT), CMDG_TEND_MINW) k_tende
                 load_state<NGF, Np>(gfP, a.gf, fp.vidP, fp.eP);
             }
 #pragma unroll
-            for (int s = 0; s < NHYP; ++s)
-                hypM[s] = NHS > 0 ? sM[(NS + NFA + NGFS + s) * NSURF + sidx]
-                                  : a.hypgrad[fp.vidM + (int64_t)Np * (s + (int64_t)NHG * e)];
+            for (int s = 0; s < NHYP; ++s) hypM[s] = sM[(NS + NFA + NGFS + s) * NSURF + sidx];
             load_state<NS, Np>(QPn, a.Q, fp.vidP, fp.eP);
 #pragma unroll
             for (int s = 0; s < NAUX; ++s) auxPn[s] = 0;
@@ -501,7 +481,6 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NTT), CMDG_TEND_MINW) k_tende
         }
         __syncthreads();
     }
-    }  // pass
     if (tid < Np) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
