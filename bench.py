@@ -302,14 +302,17 @@ def main():
         # profiles/r01_pmc_calibration_n30.json confirms for this library's 8-byte-per-lane
         # loads); only quoted for the configuration it was measured on
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                "r01_heldsuarez_n11_pmc_hbm_per_launch.json")
-        if (args.workload == "heldsuarez" and world == 1 and grid.nreal == 5808
-                and not args.filter and os.path.exists(pmc_file)):
-            pm = json.load(open(pmc_file)).get("k_%s" % dom.lower())
-            if pm and "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
-                traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"])
-                traffic_src = "profiles/r01_heldsuarez_n11_pmc_hbm_per_launch.json"
+        pmc_files = {("heldsuarez", 5808): "r01_heldsuarez_n11_pmc_hbm_per_launch.json",
+                     ("risingbubble", 8000): "r01_risingbubble_8000_pmc_hbm_per_launch.json",
+                     ("bomex", 8192): "r01_bomex_n6_8192_pmc_hbm_per_launch.json"}
+        pmc_name = pmc_files.get((args.workload, grid.nreal))
+        if pmc_name and world == 1 and not args.filter:
+            pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
+            if os.path.exists(pmc_file):
+                pm = json.load(open(pmc_file)).get("k_%s" % dom.lower())
+                if pm and "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+                    traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"])
+                    traffic_src = "profiles/" + pmc_name
         out = {
             "metric": "DG RHS DOF-updates/sec", "value": dofs / el, "unit": "DOF-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -947,8 +947,14 @@ __global__ void k_update_aux(typename P::Params prm, const double *Q, double *au
     load_state<NS, Np>(lQ, Q, n, e);
     load_state<NAUX, Np>(laux, aux, n, e);
     P::update_aux(prm, lQ, laux, t);
+    if constexpr (P::NUPD > 0) {  // the law names the entries its refresh rewrites
 #pragma unroll
-    for (int s = 0; s < NAUX; ++s) aux[n + (int64_t)Np * (s + (int64_t)NAUX * e)] = laux[s];
+        for (int s = 0; s < P::NUPD; ++s)
+            aux[n + (int64_t)Np * (P::upd_aux(s) + (int64_t)NAUX * e)] = laux[P::upd_aux(s)];
+    } else {
+#pragma unroll
+        for (int s = 0; s < NAUX; ++s) aux[n + (int64_t)Np * (s + (int64_t)NAUX * e)] = laux[s];
+    }
 }
 
 // one-time: time-invariant per-node fields the law would otherwise recompute every call
