@@ -200,3 +200,36 @@ def test_bomex_local_multirank_matches_single_rank(cm, torch):
                 assert np.abs(qn[i, s] - ref[int(g)][s]).max() / sc < 1e-11, (s, i)
     for d in dgs + [dg1]:
         d.close()
+
+
+def test_bomex_budgets_close_at_bench_size(cm, torch):
+    """Size-independent property at the bench size (16 x 16 x 32 elements, N = 6, the oracle is
+    too slow there): the device tendencies of rho and rho q_tot integrate to the prescribed
+    surface moisture flux plus the volume source of BomexTendencies."""
+    import types
+    import bench
+    args = types.SimpleNamespace(nhorz=0, nvert=8, ne=32, bomex_ne=16)
+    law, grid, _, _, _ = bench.build_workload(cm, "bomex", 0, 1, 32, args)
+    assert grid.nreal == 8192 and grid.Np == 343
+    dg = cm.dgmodel.DGModel(law, grid)
+    Q = dg.init_ode_state(0.0)
+    T = torch.zeros_like(Q)
+    dg(T, Q, 0.0, 1.0, 0.0)
+    Tn, Qn = T.cpu().numpy(), Q.cpu().numpy()
+    A, gf = dg.state_auxiliary.cpu().numpy(), dg.state_gradient_flux.cpu().numpy()
+    assert np.isfinite(Tn).all()
+    M = grid.vgeo[:grid.nreal, 9, :]
+    b = law.bomex
+    z, rho = A[:, 3] / law.ps.grav, Qn[:, 0]
+    lin = (z - b["zl_moisture"]) / (b["zh_moisture"] - b["zl_moisture"])
+    rdqt = np.where(z <= b["zl_moisture"], rho * b["dqt_peak"],
+                    np.where(z <= b["zh_moisture"], rho * (b["dqt_peak"] - b["dqt_peak"] * lin), 0.0))
+    ls = (z - b["zl_sub"]) / (b["zh_sub"] - b["zl_sub"])
+    w_s = np.where(z <= b["zl_sub"], z * b["w_sub"] / b["zl_sub"],
+                   np.where(z <= b["zh_sub"], b["w_sub"] - b["w_sub"] * ls, 0.0))
+    vol = (M * (rdqt - rho * w_s * gf[:, 3 + 7 + 2])).sum()
+    area = 3200.0 * 3200.0
+    for s in (0, 5):
+        total = (M * Tn[:, s]).sum()
+        assert abs(total - (vol + b["q_flux"] * area)) <= 1e-8 * abs(b["q_flux"] * area), s
+    dg.close()
