@@ -115,6 +115,7 @@ SYMBOLS = [
     ("cmdg_ocean_tendency_from_slow_to_fast", C.c_int, [_vp, _vp, _vp, _vp]),
     ("cmdg_ocean_reconcile_from_fast_to_slow", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("cmdg_lsrk_update", C.c_int, [_vp, _vp, _vp, _d, _d]),
+    ("cmdg_ls3n_step", C.c_int, [_vp, _vp, _vp, _vp, _d, _d, _i32, _vp, _vp, _vp]),
     ("cmdg_ssprk_step", C.c_int, [_vp, _vp, _vp, _vp, _d, _d, _i32, _vp, _vp, _vp]),
     ("cmdg_group_split_explicit_step", C.c_int,
      [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i32, _vp, _vp, _vp]),

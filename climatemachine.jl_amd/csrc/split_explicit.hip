@@ -117,6 +117,25 @@ __global__ void k_ssprk_update(const double *__restrict__ R, const double *__res
         Qstage[i] = rka1 * Q[i] + rka2 * Qstage[i] + dt * rkb * R[i];
 }
 
+// update! of LowStorageRungeKutta3NMethod.jl:201-226
+__global__ void k_ls3n_update(double *__restrict__ dQ, double *__restrict__ dR, double *__restrict__ Q,
+                              double rka1, double rka2, double rkb1, double rkb2, double dt,
+                              int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        Q[i] += rkb1 * dt * dQ[i] + rkb2 * dt * dR[i];
+        dR[i] += rka2 * dQ[i];
+        dQ[i] *= rka1;
+    }
+}
+__global__ void k_fill(double *__restrict__ a, double v, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        a[i] = v;
+}
+
 int launch_status(EngineBase *e)
 {
     hipError_t r = hipGetLastError();
@@ -159,6 +178,28 @@ int cmdg_lsrk_update(cmdg_handle h, double *dQ, double *Q, double rka_next, doub
     if (!h || !dQ || !Q) return CMDG_ERR_INVALID;
     lsrk_update(h->eng, dQ, Q, rka_next, rkb_dt);
     return set_err2(h, launch_status(h->eng));
+}
+
+int cmdg_ls3n_step(cmdg_handle h, double *Q, double *dQ, double *dR, double t, double dt,
+                   int32_t nstages, const double *rka, const double *rkb, const double *rkc)
+{
+    if (!h || !Q || !dQ || !dR || !rka || !rkb || !rkc || nstages < 1) return CMDG_ERR_INVALID;
+    EngineBase *e = h->eng;
+    const int64_t n = (int64_t)e->Np * e->ns * e->nreal;
+    hipLaunchKernelGGL(k_fill, dim3(nblocks(n)), dim3(256), 0, e->s_comp, dR, -0.0, n);
+    for (int s = 0; s < nstages; ++s) {
+        RhsCtx c;
+        c.tendency = dQ;
+        c.Qin = Q;
+        c.t = t + rkc[s] * dt;
+        c.alpha = 1.0;
+        c.beta = 1.0;  // increment = true
+        if (int r = e->rhs_async(c)) return set_err2(h, r);
+        const int sn = (s + 1) % nstages;
+        hipLaunchKernelGGL(k_ls3n_update, dim3(nblocks(n)), dim3(256), 0, e->s_comp, dQ, dR, Q,
+                           rka[2 * sn], rka[2 * sn + 1], rkb[2 * s], rkb[2 * s + 1], dt, n);
+    }
+    return set_err2(h, launch_status(e));
 }
 
 int cmdg_ssprk_step(cmdg_handle h, double *Q, double *Rstage, double *Qstage, double t, double dt,

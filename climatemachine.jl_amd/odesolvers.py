@@ -16,7 +16,8 @@ from fractions import Fraction
 __all__ = ["LSRK54CarpenterKennedy", "LSRK144NiegemannDiehlBusch", "solve",
            "LowStorageRungeKutta2N", "LSRK144_COEFFICIENTS", "StrongStabilityPreservingRungeKutta",
            "SSPRK22Heuns", "SSPRK22Ralstons", "SSPRK33ShuOsher", "SSPRK34SpiteriRuuth",
-           "SSPRK_COEFFICIENTS"]
+           "SSPRK_COEFFICIENTS", "LowStorageRungeKutta3N", "LS3NRK44Classic", "LS3NRK33Heuns",
+           "LS3N_COEFFICIENTS"]
 
 
 def _f(num, den):
@@ -117,6 +118,54 @@ def _ssp(name):
 
 SSPRK22Heuns, SSPRK22Ralstons = _ssp("SSPRK22Heuns"), _ssp("SSPRK22Ralstons")
 SSPRK33ShuOsher, SSPRK34SpiteriRuuth = _ssp("SSPRK33ShuOsher"), _ssp("SSPRK34SpiteriRuuth")
+
+
+# (RKA, RKB, RKC) of LowStorageRungeKutta3NMethod.jl:228-345: the classic fourth-order scheme and
+# Heun's third-order scheme in Fyfe's 3N storage form
+LS3N_COEFFICIENTS = {
+    "LS3NRK44Classic": (((0.0, 0.0), (0.0, 1.0), (-1 / 2, 0.0), (2.0, -6.0)),
+                        ((1 / 2, 0.0), (1 / 2, -1 / 2), (1.0, 0.0), (_f(1, 6), _f(1, 6))),
+                        (0.0, 1 / 2, 1 / 2, 1.0)),
+    "LS3NRK33Heuns": (((0.0, 0.0), (0.0, 1.0), (-1.0, _f(1, 3))),
+                      ((_f(1, 3), 0.0), (_f(2, 3), -_f(1, 3)), (3 / 4, 1 / 4)),
+                      (0.0, _f(1, 3), _f(2, 3))),
+}
+
+
+class LowStorageRungeKutta3N:
+    """``LowStorageRungeKutta3N(f, RKA, RKB, RKC, RKW, Q; dt, t0)``
+    (LowStorageRungeKutta3NMethod.jl:60-120); the stage loop is ``cmdg_ls3n_step``."""
+
+    def __init__(self, dg, RKA, RKB, RKC, Q, dt=0.0, t0=0.0):
+        import numpy as np
+        self.dg, self.dt, self.t, self.steps = dg, dt, t0, 0
+        self.RKA = np.ascontiguousarray(RKA, dtype=np.float64)
+        self.RKB = np.ascontiguousarray(RKB, dtype=np.float64)
+        self.RKC = np.ascontiguousarray(RKC, dtype=np.float64)
+        self.dQ = dg.create_state(Q.shape[1])
+        self.dR = dg.create_state(Q.shape[1])
+
+    def dostep(self, Q, nsteps=1, dt=None):
+        import ctypes as C
+        from . import _lib
+        dt = self.dt if dt is None else dt
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        self.dg._torch_ready()
+        for i in range(int(nsteps)):
+            _lib.check(self.dg.L.cmdg_ls3n_step(
+                self.dg.handle, Q.data_ptr(), self.dQ.data_ptr(), self.dR.data_ptr(),
+                float(self.t + i * dt), float(dt), len(self.RKC), p(self.RKA), p(self.RKB),
+                p(self.RKC)), self.dg.handle)
+
+
+def _ls3n(name):
+    def make(dg, Q, dt=0.0, t0=0.0):
+        return LowStorageRungeKutta3N(dg, *LS3N_COEFFICIENTS[name], Q, dt=dt, t0=t0)
+    make.__name__ = name
+    return make
+
+
+LS3NRK44Classic, LS3NRK33Heuns = _ls3n("LS3NRK44Classic"), _ls3n("LS3NRK33Heuns")
 
 
 def solve(Q, solver, timeend=None, numberofsteps=0, adjustfinalstep=True):

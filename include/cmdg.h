@@ -332,6 +332,15 @@ int cmdg_lsrk_update(cmdg_handle h, double *dQ, double *Q, double rka_next, doub
 int cmdg_ssprk_step(cmdg_handle h, double *Q, double *Rstage, double *Qstage, double t, double dt,
                     int32_t nstages, const double *rka, const double *rkb, const double *rkc);
 
+/* dostep!(Q, lsrk3n::LowStorageRungeKutta3N, p, time)
+ * (src/Numerics/ODESolvers/LowStorageRungeKutta3NMethod.jl:153-226, Fyfe 1966): dR = -0; per
+ * stage dQ += rhs(Q, t + rkc[s] dt), then Q += rkb[2 s] dt dQ + rkb[2 s + 1] dt dR,
+ * dR += rka[2 s' + 1] dQ, dQ *= rka[2 s'] with s' = (s + 1) mod nstages.  rka and rkb are the
+ * (nstages, 2) matrices row-major; dQ (zero before the first step) and dR are caller-owned
+ * arrays of Q's shape. */
+int cmdg_ls3n_step(cmdg_handle h, double *Q, double *dQ, double *dR, double t, double dt,
+                   int32_t nstages, const double *rka, const double *rkb, const double *rkc);
+
 /* dostep!(Qslow, split::SplitExplicitSolver, param, time) (SplitExplicitMethod.jl:70-177): one
  * slow step of size dt_slow whose every stage sub-steps the fast model with full LSRK steps
  * of at most dt_fast.  dQ_slow / dQ_fast are the LSRK tendency accumulators (zero before the

@@ -416,6 +416,19 @@ def ssprk_step(dg, Q, Rstage, Qstage, t, dt, rka, rkb, rkc):
     Q[:nr] = Qstage[:nr]
 
 
+def ls3n_step(dg, Q, dQ, dR, t, dt, rka, rkb, rkc):
+    """``dostep!`` of LowStorageRungeKutta3NMethod.jl:153-199 with the ``update!`` kernel of
+    :201-226 on the real elements."""
+    nr, ns = dg.grid.nreal, len(rkc)
+    dR[:nr] = -0.0
+    for s in range(ns):
+        dg(dQ, Q, t + rkc[s] * dt, 1.0, 1.0)             # rhs!(...; increment = true)
+        sn = (s + 1) % ns
+        Q[:nr] += rkb[s][0] * dt * dQ[:nr] + rkb[s][1] * dt * dR[:nr]
+        dR[:nr] += rka[sn][1] * dQ[:nr]
+        dQ[:nr] *= rka[sn][0]
+
+
 def solve(dg, Q, dt, timeend, t0=0.0):
     """``solve!`` with ``adjustfinalstep = true`` (ODESolvers.jl:49-158)."""
     dQ = np.zeros_like(Q)

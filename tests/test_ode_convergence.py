@@ -63,6 +63,60 @@ def test_ssprk_order_oracle(oracle, method, order):
     assert abs(rate - order) <= ATOL, (errors, rate)
 
 
+@pytest.mark.parametrize("method,order", [("LS3NRK44Classic", 4), ("LS3NRK33Heuns", 3)])
+def test_ls3n_order_oracle(oracle, method, order):
+    rka, rkb, rkc = cm.odesolvers.LS3N_COEFFICIENTS[method]
+
+    class Rhs:
+        grid = types.SimpleNamespace(nreal=1)
+
+        def __call__(self, dQ, Q, t, alpha, beta):
+            dQ[...] = alpha * (Q * np.cos(t)) + beta * dQ
+
+    errors = []
+    for dt in DTS:
+        Q = Q0.reshape(1, 1, -1).copy()
+        dQ, dR = np.zeros_like(Q), np.zeros_like(Q)
+        for i in range(int(round(FINAL / dt))):
+            oracle.ls3n_step(Rhs(), Q, dQ, dR, i * dt, dt, rka, rkb, rkc)
+        errors.append(np.abs(Q.reshape(-1) - Q0 * np.exp(np.sin(FINAL))).max())
+    rate = np.log2(errors[0] / errors[1])
+    assert abs(rate - order) <= ATOL, (errors, rate)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["LS3NRK44Classic", "LS3NRK33Heuns", "SSPRK33ShuOsher"])
+def test_other_steppers_match_oracle_on_the_device(oracle, method):
+    """cmdg_ls3n_step / cmdg_ssprk_step against the oracle's restatement on the advection-diffusion
+    test problem."""
+    import torch
+    from helpers import pseudo1d_setup, rel_linf
+    assert torch.cuda.is_available(), "no HIP device: the product path has no CPU fallback"
+    law, grid, dt = pseudo1d_setup(Ne=3, N=4)
+    odg = oracle.OracleDGModel(law, grid)
+    dg = cm.dgmodel.DGModel(law, grid)
+    Q0h = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    Qo = Q0h.copy()
+    Q = torch.from_numpy(Q0h.copy()).cuda()
+    torch.cuda.synchronize()
+    if method.startswith("LS3N"):
+        rka, rkb, rkc = cm.odesolvers.LS3N_COEFFICIENTS[method]
+        dQ, dR = np.zeros_like(Qo), np.zeros_like(Qo)
+        for i in range(3):
+            oracle.ls3n_step(odg, Qo, dQ, dR, i * dt, dt, rka, rkb, rkc)
+        solver = getattr(cm.odesolvers, method)(dg, Q, dt=dt)
+    else:
+        rka, rkb, rkc = cm.odesolvers.SSPRK_COEFFICIENTS[method]
+        R, Qs = np.zeros_like(Qo), np.zeros_like(Qo)
+        for i in range(3):
+            oracle.ssprk_step(odg, Qo, R, Qs, i * dt, dt, rka, rkb, rkc)
+        solver = getattr(cm.odesolvers, method)(dg, Q, dt=dt)
+    solver.dostep(Q, nsteps=3)
+    dg.synchronize()
+    assert rel_linf(Q.cpu().numpy(), Qo) < 1e-12
+    dg.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("method", ["LSRK54CarpenterKennedy", "LSRK144NiegemannDiehlBusch"])
 def test_lsrk_order_device_update_kernel(oracle, method):
