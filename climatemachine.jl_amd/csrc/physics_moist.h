@@ -45,7 +45,7 @@ struct MoistAtmos {
     // reference reads them too (gradient argument / flux) or where the values are the same by
     // construction (source)
     static constexpr bool HAS_UPDATE_AUX = true, FUSE_UPDATE_AUX = false, HAS_SOURCE = true;
-    static constexpr bool HAS_COURANT = false, HAS_PENALTY = false;
+    static constexpr bool HAS_COURANT = true, HAS_PENALTY = false;
     static constexpr int NUPD = 4;
     __host__ __device__ static constexpr int upd_aux(int i) { return OMOIST + i; }
     static constexpr int NDER = 0;
@@ -221,10 +221,50 @@ struct MoistAtmos {
                                           const double *)
     {
     }
-    __device__ static double courant(const Params &, int, const double *, const double *,
-                                     const double *, double, double, double, int)
+    // local Courant numbers of src/Atmos/Model/courant.jl:12-83 (kind 0 advective, 1
+    // nondiffusive with the moist sound speed, 2 diffusive with the closure's viscosity)
+    __device__ static double courant(const Params &m, int kind, const double *Q, const double *aux,
+                                     const double *gf, double dx, double dt, double, int direction)
     {
-        return 0.0;
+        double k[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) k[d] = aux[OPHI + 1 + d] / m.grav;
+        if (kind == 2) {
+            double nu[3], tau[9];
+            turbulence_tensors(m, Q, gf, aux, nu, tau);
+            double normnu;
+            if constexpr (CLOSURE == 0) {
+                normnu = nu[0];
+            } else {
+                const double dk = nu[0] * k[0] + nu[1] * k[1] + nu[2] * k[2];
+                if (direction == DIR_VERTICAL) {
+                    normnu = dk;
+                } else {
+                    double v[3];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                        v[d] = direction == DIR_HORIZONTAL ? nu[d] - dk * k[d] : nu[d];
+                    normnu = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                }
+            }
+            return dt * normnu / (dx * dx);
+        }
+        const double dotk = Q[1] * k[0] + Q[2] * k[1] + Q[3] * k[2];
+        double normu;
+        if (direction == DIR_VERTICAL) {
+            normu = fabs(dotk) / Q[0];
+        } else {
+            double v[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                v[d] = direction == DIR_HORIZONTAL ? (Q[1 + d] - dotk * k[d]) / Q[0] : Q[1 + d] / Q[0];
+            normu = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        }
+        if (kind == 0) return dt * normu / dx;
+        Thermo ts;
+        thermo_state(m, Q, aux, ts);
+        const double gamma = ts.cp_m / ts.cv_m;
+        return dt * (normu + sqrt(gamma * ts.R_m * ts.T)) / dx;
     }
 
     // ---- fluxes ----------------------------------------------------------------------

@@ -476,6 +476,47 @@ static void mo_update_aux(const void *p_, const double *Q, double *aux, double t
     moist_update((const moist_t *)p_, Q, aux);
 }
 
+/* src/Atmos/Model/courant.jl:12-83 */
+static double mo_courant(const void *p_, int kind, const double *Q, const double *aux, const double *gf,
+                         double dx, double dt, double t, int direction)
+{
+    const moist_t *m = (const moist_t *)p_;
+    (void)t;
+    double k[3];
+    for (int d = 0; d < 3; ++d) k[d] = aux[OPHI + 1 + d] / m->grav;
+    if (kind == 2) {
+        double nu[3], tau[9], normnu;
+        turbulence_tensors(m, Q, gf, aux, nu, tau);
+        if (m->closure == 0) {
+            normnu = nu[0];
+        } else {
+            const double dk = nu[0] * k[0] + nu[1] * k[1] + nu[2] * k[2];
+            if (direction == ORC_VERTICAL) {
+                normnu = dk;
+            } else {
+                double v[3];
+                for (int d = 0; d < 3; ++d) v[d] = direction == ORC_HORIZONTAL ? nu[d] - dk * k[d] : nu[d];
+                normnu = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            }
+        }
+        return dt * normnu / (dx * dx);
+    }
+    const double dotk = Q[1] * k[0] + Q[2] * k[1] + Q[3] * k[2];
+    double normu;
+    if (direction == ORC_VERTICAL) {
+        normu = fabs(dotk) / Q[0];
+    } else {
+        double v[3];
+        for (int d = 0; d < 3; ++d)
+            v[d] = direction == ORC_HORIZONTAL ? (Q[1 + d] - dotk * k[d]) / Q[0] : Q[1 + d] / Q[0];
+        normu = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    }
+    if (kind == 0) return dt * normu / dx;
+    thermo_t ts;
+    thermo_state(m, Q, aux, &ts);
+    return dt * (normu + soundspeed(&ts)) / dx;
+}
+
 /* the saturation adjustment on its own, for the thermodynamic tests */
 double orc_moist_saturation_adjustment(const orc_physics *ph, double e_int, double rho, double q_tot,
                                        double *q_liq, double *q_ice, double *e_int_back)
@@ -526,5 +567,6 @@ orc_physics *orc_moist_new(const int *ip, const double *dp, int nf_first)
     ph->boundary_state_divergence = mo_bdiv;
     ph->boundary_state_higher_order = mo_bhigher;
     ph->update_aux = mo_update_aux;
+    ph->courant = mo_courant;
     return ph;
 }

@@ -233,3 +233,26 @@ def test_bomex_budgets_close_at_bench_size(cm, torch):
         total = (M * Tn[:, s]).sum()
         assert abs(total - (vol + b["q_flux"] * area)) <= 1e-8 * abs(b["q_flux"] * area), s
     dg.close()
+
+
+def test_moist_courant_numbers_match_oracle(cm, oracle, torch):
+    """src/Atmos/Model/courant.jl with the moist sound speed; calculate_dt as the LES driver uses
+    it (nondiffusive Courant number)."""
+    from helpers import bomex_setup
+    law, grid = bomex_setup(nx=3, ny=2, nz=6)
+    law.maxiter, law.tolerance = 40, 1e-11
+    odg = oracle.OracleDGModel(law, grid)
+    dg = cm.dgmodel.DGModel(law, grid)
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    T = np.zeros_like(Q0)
+    odg(T, Q0.copy(), 0.0, 1.0, 0.0)                  # fills the gradient flux (eddy viscosity)
+    Qg = _gpu(torch, Q0)
+    Tg = torch.zeros_like(Qg)
+    dg(Tg, Qg, 0.0, 1.0, 0.0)
+    for kind in (0, 1, 2):
+        for d in (0, 1, 2):
+            o = oracle.courant(kind, odg, Q0, 0.3, 0.0, d)
+            g = dg.courant(kind, Qg, 0.3, 0.0, d)
+            assert abs(g - o) <= 1e-11 * abs(o), (kind, d, g, o)
+    assert abs(dg.calculate_dt(Qg, 0.35) - oracle.calculate_dt(odg, Q0, 0.35)) <= 1e-11
+    dg.close()
