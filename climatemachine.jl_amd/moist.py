@@ -29,7 +29,9 @@ __all__ = ["MoistParameters", "MoistAtmosModel", "DensityCurrentSetup", "MoistBu
            "CLOSURE_CONSTANT", "CLOSURE_SMAGORINSKY", "CLOSURE_ANISO_MIN_DISS"]
 
 CLOSURE_CONSTANT, CLOSURE_SMAGORINSKY, CLOSURE_ANISO_MIN_DISS = 0, 1, 2
-# source bits next to SRC_GRAVITY = 1 and the boundary kind of the BOMEX surface
+# source bits next to SRC_GRAVITY = 1 and the boundary kind of the BOMEX surface.  With
+# u_slope = 0 BomexSponge is the library's RayleighSponge (relaxation to (u_geo, v_geo, 0)) and
+# BomexGeostrophic its GeostrophicForcing (tendencies_momentum.jl:74-130): same formulas.
 SRC_BOMEX_TENDENCIES, SRC_BOMEX_SPONGE, SRC_BOMEX_GEOSTROPHIC = 2, 4, 8
 BC_BOMEX_SURFACE = 2
 
