@@ -52,16 +52,26 @@ class SimpleBox:
     def init_state(self, m, x, y, z, t):
         """``ocean_init_state!`` (simple_box_problem.jl:170-190) with ``barotropic_state!`` /
         ``baroclinic_deviation`` of the ``Fixed`` box (:192-222)."""
-        assert self.rotation == FIXED, "analytic solution restated for the non-rotating box"
         kx, kz = 2 * np.pi / self.Lx, 2 * np.pi / self.H
         gH = m.grav * self.H
-        Mx = np.array([[-m.nu_h * kx ** 2, gH * kx], [-kx, 0.0]])
-        A = expm(Mx * t) @ np.array([1.0, 1.0])
-        Ub = A[0] * np.sin(kx * x)
-        eta = A[1] * np.cos(kx * x)
         lam = m.nu_h * kx ** 2 + m.nu_z * kz ** 2
-        u0 = np.exp(-lam * t) * np.cos(kz * z) * np.sin(kx * x)
-        return u0 + Ub / self.H, 0.0 * x, eta, 0.0 * x
+        if self.rotation == FIXED:
+            Mx = np.array([[-m.nu_h * kx ** 2, gH * kx], [-kx, 0.0]])
+            A = expm(Mx * t) @ np.array([1.0, 1.0])
+            Ub, Vb, eta = A[0] * np.sin(kx * x), 0.0 * x, A[1] * np.cos(kx * x)
+            u0, v0 = np.exp(-lam * t) * np.cos(kz * z) * np.sin(kx * x), 0.0 * x
+        else:
+            # barotropic_state!(::Rotating) / baroclinic_deviation(::Rotating) (:224-276)
+            assert self.rotation == ROTATING, "analytic solution restated for f = 0 and f = f_o"
+            f = m.f_o
+            Mx = np.array([[-m.nu_h * kx ** 2, f, gH * kx], [-f, -m.nu_h * kx ** 2, 0.0],
+                           [-kx, 0.0, 0.0]])
+            A = expm(Mx * t) @ np.array([1.0, 1.0, 1.0])
+            Ub, Vb, eta = A[0] * np.sin(kx * x), A[1] * np.sin(kx * x), A[2] * np.cos(kx * x)
+            B = expm(np.array([[-lam, f], [-f, -lam]]) * t) @ np.array([1.0, 1.0])
+            u0 = B[0] * np.cos(kz * z) * np.sin(kx * x)
+            v0 = B[1] * np.cos(kz * z) * np.sin(kx * x)
+        return u0 + Ub / self.H, v0 + Vb / self.H, eta, 0.0 * x
 
 
 class OceanGyre:
@@ -196,15 +206,23 @@ class ShallowWaterModel:
         """``ocean_init_state!(::SWModel, ::SimpleBox, ...)`` (simple_box_problem.jl:128-146):
         the barotropic mode ``U = A1 sin(kx x)``, ``eta = A2 cos(kx x)``, ``A = exp(M t) [1, 1]``."""
         p = self.problem
-        assert p.rotation == FIXED
         x = grid.vgeo[:, 12, :]
         kx = 2 * np.pi / p.Lx
         gH = self.grav * p.H
-        A = expm(np.array([[-self.nu * kx ** 2, gH * kx], [-kx, 0.0]]) * t) @ np.array([1.0, 1.0])
         Q = np.zeros((grid.nelem, 3, grid.Np))
-        Q[:, 0] = A[1] * np.cos(kx * x)
-        Q[:, 1] = A[0] * np.sin(kx * x)
-        Q[:, 2] = -0.0
+        if p.rotation == FIXED:
+            A = expm(np.array([[-self.nu * kx ** 2, gH * kx], [-kx, 0.0]]) * t) @ np.array([1.0, 1.0])
+            Q[:, 0] = A[1] * np.cos(kx * x)
+            Q[:, 1] = A[0] * np.sin(kx * x)
+            Q[:, 2] = -0.0
+        else:      # barotropic_state!(::Rotating) (simple_box_problem.jl:224-243)
+            assert p.rotation == ROTATING
+            f = self.f_o
+            A = expm(np.array([[-self.nu * kx ** 2, f, gH * kx], [-f, -self.nu * kx ** 2, 0.0],
+                               [-kx, 0.0, 0.0]]) * t) @ np.array([1.0, 1.0, 1.0])
+            Q[:, 0] = A[2] * np.cos(kx * x)
+            Q[:, 1] = A[0] * np.sin(kx * x)
+            Q[:, 2] = A[1] * np.sin(kx * x)
         return Q
 
 

@@ -264,14 +264,15 @@ def heat_eqn_setup(level=1, direction=0, N=4, rank=0, size=1):
     return law, grid, 0.01 / nsteps, nsteps
 
 
-def split_explicit_setup(coupled=True, Nx=5, Ny=5, Nz=8, N=4, N_extrusion=None, rank=0, size=1):
+def split_explicit_setup(coupled=True, Nx=5, Ny=5, Nz=8, N=4, N_extrusion=None, rank=0, size=1,
+                         rotating=False):
     """test/Ocean/SplitExplicit/hydrostatic_spindown.jl:3-140 (SplitExplicitSolver variant):
     SimpleBox 1e6 x 1e6 x 400 m, 3-D HBModel (c_h = 1, alpha_T = kappa = 0, default Coriolis
     parameters but a Fixed box, so f = -0) + 2-D ShallowWaterModel (ConstantViscosity(nu_h),
     c = 1); periodic in x and y; the barotropic model on the one-layer extrusion of the 2-D grid."""
     O = cm.ocean
     Lx, Ly, H = 1e6, 1e6, 400.0
-    problem = O.SimpleBox(Lx, Ly, H)
+    problem = O.SimpleBox(Lx, Ly, H, rotation=O.ROTATING if rotating else O.FIXED)
     law3 = O.HydrostaticBoussinesqModel(problem, c_h=1.0, alpha_T=0.0, kappa_h=0.0, kappa_z=0.0,
                                         coupled=coupled)
     law2 = O.ShallowWaterModel(problem, law3.nu_h, advection=False, coupled=coupled, c=1.0)

@@ -243,3 +243,52 @@ def test_partitioned_split_explicit_matches_single_rank(cm, torch, size):
         d3.close()
     for d2 in fasts + [dg2]:
         d2.close()
+
+
+def test_rotating_box_split_explicit_meets_the_reference_bound(cm, oracle, torch):
+    """test/Ocean/SplitExplicit/test_coriolis.jl: the rotating box (f = f_o in both models),
+    coupled, 15 simulated days of 300 s steps; the reference's criterion is the distance to the
+    analytic inertia-gravity solution, < 0.005 for the 3-D and the 2-D state
+    (split_explicit.jl:100-106)."""
+    O = cm.ocean
+    law3, g3, law2, g2 = split_explicit_setup(True, rotating=True, N_extrusion=1)
+    dg3 = cm.dgmodel.DGModel(law3, g3)
+    keep = O.install_hydrostatic_boussinesq_hooks(dg3)
+    dg2 = cm.dgmodel.DGModel(law2, g2,
+                             numerical_flux_first_order=cm.balancelaws.CentralNumericalFluxFirstOrder)
+    Q3g, Q2g = dg3.init_ode_state(0.0), dg2.init_ode_state(0.0)
+    se = O.SplitExplicitSolver(dg3, dg2, Q3g, Q2g, 300.0, 300.0)
+    se.dostep(Q3g, Q2g, 15 * 288)
+    for law, g, Q, dg in ((law3, g3, Q3g, dg3), (law2, g2, Q2g, dg2)):
+        Qn = Q.cpu().numpy()
+        Qe = law.init_state_prognostic(g, dg.state_auxiliary.cpu().numpy(), 15 * 86400.0)
+        err = np.sqrt(oracle.weighted_norm2_local(g, Qn, Qe) / oracle.weighted_norm2_local(g, Qe))
+        assert err < 0.005, err
+    assert np.abs(Q3g.cpu().numpy()[:, 1]).max() > 1e-3       # the Coriolis force built up v
+    dg3.set_rhs_hooks()
+    for f in keep:
+        f.close()
+    dg3.close()
+    dg2.close()
+
+
+def test_rotating_split_explicit_steps_match_oracle(cm, oracle, torch):
+    law3, g3, law2, g2 = split_explicit_setup(True, Nx=3, Ny=2, Nz=3, rotating=True)
+    o3, o2 = _oracle_pair(cm, oracle, law3, g3, law2, g2)
+    dg3, dg2, keep = _device_pair(cm, torch, law3, g3, law2, g2)
+    Q3 = law3.init_state_prognostic(g3, o3.state_auxiliary, 0.0)
+    Q2 = law2.init_state_prognostic(g2, o2.state_auxiliary, 0.0)
+    Q3g, Q2g = _gpu(torch, Q3), _gpu(torch, Q2)
+    se_o = oracle.SplitExplicitOracle(o3, o2, Q3, Q2, 1800.0, 300.0)
+    se = cm.ocean.SplitExplicitSolver(dg3, dg2, Q3g, Q2g, 1800.0, 300.0)
+    t = 0.0
+    for _ in range(3):
+        se_o.dostep(Q3, Q2, t)
+        t += 1800.0
+    se.dostep(Q3g, Q2g, 3)
+    Qn3, Qn2 = Q3g.cpu().numpy(), Q2g.cpu().numpy()
+    for s in (0, 1, 2):
+        assert _scaled(Qn3[:, s], Q3[:, s]) < TOL, s
+    for s in (0, 1, 2):
+        assert _scaled(Qn2[:, s], Q2[:, s]) < TOL, s
+    _close(dg3, dg2, keep)
