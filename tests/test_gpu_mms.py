@@ -67,3 +67,19 @@ def test_mms_reference_errors_on_the_device(cm, oracle, torch, level):
     ref = GOLD["dim3"][level - 1]
     assert abs(err - ref) <= GOLD["rtol"] * ref, (err, ref)
     dg.close()
+
+
+def test_driver_mms3_value_on_the_device(cm, oracle, torch):
+    """test/Driver/mms3.jl through solve(..., adjustfinalstep=False): 801 steps (see
+    tests/test_mms_oracle.py)."""
+    law, grid, dt, _ = mms_atmos_setup(level=1)
+    dg = cm.dgmodel.DGModel(law, grid)
+    Q = dg.init_ode_state(0.0)
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+    cm.odesolvers.solve(Q, solver, timeend=1.0, adjustfinalstep=False)
+    assert solver.steps == 801
+    Qe = law.init_state_prognostic(grid, dg.state_auxiliary.cpu().numpy(), 1.0)
+    err = np.sqrt(oracle.weighted_norm2_local(grid, Q.cpu().numpy(), Qe))
+    ref = GOLD["driver_mms3"]
+    assert abs(err - ref) <= GOLD["rtol"] * ref, (err, ref)
+    dg.close()

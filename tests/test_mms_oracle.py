@@ -44,3 +44,23 @@ def test_mms_level1_matches_reference_error(oracle):
     err = np.sqrt(oracle.weighted_norm2_local(grid, Q, Qe))
     assert abs(err - GOLD["dim3"][0]) <= GOLD["rtol"] * GOLD["dim3"][0]
     assert abs(err - GOLD["dim3"][0]) <= 1e-11 * GOLD["dim3"][0]      # observed 2e-13
+
+
+def test_driver_mms3_value_with_the_unadjusted_final_step(oracle):
+    """test/Driver/mms3.jl: `invoke!` runs `solve!(...; adjustfinalstep = false)`; 800 additions of
+    dt = 1/800 fall short of 1 by 2e-14, so the loop `while time < timeend` takes step 801.  The
+    stored distance to the exact state at t = 1 is that of the state at t = 1.00125."""
+    law, grid, dt, nsteps = mms_atmos_setup(level=1)
+    dg = oracle.OracleDGModel(law, grid)
+    Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
+    dQ = np.zeros_like(Q)
+    t, n = 0.0, 0
+    while t < 1.0:                       # general_dostep! without adjustment (ODESolvers.jl:49-73)
+        oracle.lsrk54_step(dg, Q, dQ, t, dt)
+        t = t + dt
+        n += 1
+    assert n == 801
+    Qe = law.init_state_prognostic(grid, dg.state_auxiliary, 1.0)
+    err = np.sqrt(oracle.weighted_norm2_local(grid, Q, Qe))
+    ref = GOLD["driver_mms3"]
+    assert abs(err - ref) <= 1e-10 * ref, (err, ref)
