@@ -17,6 +17,8 @@ from .mesh.grids import _x1, _x2, _x3
 
 EveryDirection, HorizontalDirection, VerticalDirection = 0, 1, 2
 RusanovNumericalFlux, CentralNumericalFluxFirstOrder = 0, 1
+# methods of the dry AtmosModel (src/Atmos/Model/AtmosModel.jl:1006, :1154)
+RoeNumericalFlux, HLLCNumericalFlux = 2, 3
 
 PHYSICS_ADVECTION_DIFFUSION = 1
 PHYSICS_DRY_ATMOS = 2
@@ -27,7 +29,8 @@ PHYSICS_MOIST_ATMOS = 6
 
 __all__ = [
     "EveryDirection", "HorizontalDirection", "VerticalDirection",
-    "RusanovNumericalFlux", "CentralNumericalFluxFirstOrder",
+    "RusanovNumericalFlux", "CentralNumericalFluxFirstOrder", "RoeNumericalFlux",
+    "HLLCNumericalFlux",
     "InhomogeneousBC", "HomogeneousBC", "AdvectionDiffusion", "Pseudo1D",
     "ConstantHyperDiffusion", "DirectionSplitBox",
 ]

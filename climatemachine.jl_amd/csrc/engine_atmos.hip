@@ -27,6 +27,15 @@ static EngineBase *pick(const cmdg_desc *d, std::string &err)
               "constant viscosity only";
         return nullptr;
     }
+    if (d->nf_first >= NF_ROE) {  // the law's own Roe / HLLC methods
+        if constexpr (NQ == 5) {
+            if (!orient && !ref && !hyp && d->iparam[14] == 0 && !mms)
+                return make_engine<DryAtmos<false, false, false, false, true>, NQ>(d);
+        }
+        err = "DryAtmos: Roe / HLLC numerical fluxes are compiled for N = 4, NoOrientation, "
+              "NoReferenceState, constant viscosity";
+        return nullptr;
+    }
     if (d->iparam[14] == 1) {  // SmagorinskyLilly (AtmosLES configurations)
         if (orient && ref && !hyp) return make_engine<DryAtmos<true, true, false, true>, NQ>(d);
         err = "DryAtmos: SmagorinskyLilly is compiled with orientation + reference state, no hyperdiffusion";

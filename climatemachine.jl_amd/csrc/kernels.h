@@ -137,6 +137,14 @@ template <class P>
 struct node_cache_size<P, std::void_t<decltype(P::NCACHE)>> : std::integral_constant<int, P::NCACHE> {
 };
 
+// laws that carry numerical_flux_first_order! methods of their own (P::LAW_NF)
+template <class P, class = void>
+struct has_law_nf : std::false_type {
+};
+template <class P>
+struct has_law_nf<P, std::void_t<decltype(P::LAW_NF)>> : std::integral_constant<bool, P::LAW_NF> {
+};
+
 // numerical_flux_first_order!  NumericalFluxes.jl:223-285 (Rusanov) / :300-340 (central)
 template <class P>
 __device__ __forceinline__ void nf_first_order(const typename P::Params &prm, int nf,
@@ -146,6 +154,12 @@ __device__ __forceinline__ void nf_first_order(const typename P::Params &prm, in
                                                int facedir, const double *cacheM = nullptr)
 {
     constexpr int NS = P::NS;
+    if constexpr (has_law_nf<P>::value) {
+        if (nf >= NF_ROE) {
+            P::numerical_flux_law(prm, nf, fluxn, n, QM, auxM, QP, auxP, t, facedir);
+            return;
+        }
+    }
     Vec<3 * NS> FM, FP;
     Vec<NS> wM, wP;
     FM.negzero();

@@ -31,8 +31,11 @@ struct AtmosParams {
     int withdiv, zero_h;  // WithDivergence stress; total_specific_enthalpy overridden to zero
 };
 
-template <bool ORIENT, bool REF, bool HYPER, bool SMAG = false>
+template <bool ORIENT, bool REF, bool HYPER, bool SMAG = false, bool LAWNF = false>
 struct DryAtmos {
+    // RoeNumericalFlux / HLLCNumericalFlux live in a variant of their own so that the
+    // kernels of every other configuration keep their register budget
+    static constexpr bool LAW_NF = LAWNF;
     static_assert(!(SMAG && HYPER), "gradient-variable order of this combination is not laid out");
     static_assert(!SMAG || ORIENT, "SmagorinskyLilly needs an orientation (buoyancy correction)");
     using Params = AtmosParams;
@@ -119,7 +122,7 @@ struct DryAtmos {
 
     // ---- local Courant numbers: src/Atmos/Model/courant.jl:12-83 ------------------------
     // the manufactured-solution pieces (source, InitStateBC) exist in the plain variant only
-    static constexpr bool MMS_VARIANT = !ORIENT && !REF && !HYPER && !SMAG;
+    static constexpr bool MMS_VARIANT = !ORIENT && !REF && !HYPER && !SMAG && !LAWNF;
     static constexpr bool HAS_COURANT = true;
     static constexpr bool HAS_PENALTY = false;  // update_penalty! is the default no-op
     __device__ static void update_penalty(const Params &, double *, const double *, const double *,
@@ -510,6 +513,104 @@ struct DryAtmos {
         const double ss = soundspeed(m, air_T(m, internal_energy(m, Q, aux)));
 #pragma unroll
         for (int s = 0; s < 5; ++s) ws[s] = uN + ss;
+    }
+    // RoeNumericalFlux (AtmosModel.jl:1003-1130, DryModel only) and HLLCNumericalFlux
+    // (:1154-1276); adds the normal flux to fluxn
+    __device__ static double roe_average(double sM, double sP, double vM, double vP)
+    {
+        return (sM * vM + sP * vP) / (sM + sP);
+    }
+    __device__ static void numerical_flux_law(const Params &m, int nf, double *fluxn,
+                                              const double *n, const double *QM,
+                                              const double *auxM, const double *QP,
+                                              const double *auxP, double t, int facedir)
+    {
+        double FM[15], FP[15];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) FM[i] = FP[i] = -0.0;
+        flux_first_order(m, FM, QM, auxM, t, facedir);
+        flux_first_order(m, FP, QP, auxP, t, facedir);
+        const double rM = QM[0], rP = QP[0];
+        double uM[3], uP[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            uM[d] = QM[1 + d] / rM;
+            uP[d] = QP[1 + d] / rP;
+        }
+        const double TM = air_T(m, internal_energy(m, QM, auxM));
+        const double TP = air_T(m, internal_energy(m, QP, auxP));
+        const double pM = air_p(m, TM, rM), pP = air_p(m, TP, rP);
+        const double cM = soundspeed(m, TM), cP = soundspeed(m, TP);
+        const double unM = uM[0] * n[0] + uM[1] * n[1] + uM[2] * n[2];
+        const double unP = uP[0] * n[0] + uP[1] * n[1] + uP[2] * n[2];
+        if (nf == NF_ROE) {
+            const double nh0 = n[0] / 2, nh1 = n[1] / 2, nh2 = n[2] / 2;
+#pragma unroll
+            for (int s = 0; s < 5; ++s)
+                fluxn[s] += (FM[3 * s] + FP[3 * s]) * nh0 + (FM[3 * s + 1] + FP[3 * s + 1]) * nh1 +
+                            (FM[3 * s + 2] + FP[3 * s + 2]) * nh2;
+            const double Phi = ORIENT ? auxM[OPHI] : 0.0;
+            const double eM = QM[4] / rM, eP = QP[4] / rP;
+            const double hM = m.zero_h ? 0.0 : eM + m.R_d * TM;
+            const double hP = m.zero_h ? 0.0 : eP + m.R_d * TP;
+            const double sM = sqrt(rM), sP = sqrt(rP);
+            const double rt = sqrt(rM * rP);
+            double ut[3], du[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                ut[d] = roe_average(sM, sP, uM[d], uP[d]);
+                du[d] = uP[d] - uM[d];
+            }
+            const double ht = roe_average(sM, sP, hM, hP);
+            const double ct = sqrt(roe_average(sM, sP, cM * cM, cP * cP));
+            const double utn = ut[0] * n[0] + ut[1] * n[1] + ut[2] * n[2];
+            const double dr = rP - rM, dp = pP - pM;
+            const double dun = du[0] * n[0] + du[1] * n[1] + du[2] * n[2];
+            const double w1 = fabs(utn - ct) * (dp - rt * ct * dun) / (2 * (ct * ct));
+            const double w2 = fabs(utn + ct) * (dp + rt * ct * dun) / (2 * (ct * ct));
+            const double w3 = fabs(utn) * (dr - dp / (ct * ct));
+            const double w4 = fabs(utn) * rt;
+            fluxn[0] -= (w1 + w2 + w3) / 2;
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                fluxn[1 + d] -= (w1 * (ut[d] - ct * n[d]) + w2 * (ut[d] + ct * n[d]) + w3 * ut[d] +
+                                 w4 * (du[d] - dun * n[d])) / 2;
+            const double utut = ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2];
+            const double utdu = ut[0] * du[0] + ut[1] * du[1] + ut[2] * du[2];
+            fluxn[4] -= (w1 * (ht - ct * utn) + w2 * (ht + ct * utn) +
+                         w3 * (utut / 2 + Phi - m.T_0 * m.cv_d) + w4 * (utdu - utn * dun)) / 2;
+            return;
+        }
+        double fnM[5], fnP[5];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            fnM[s] = FM[3 * s] * n[0] + FM[3 * s + 1] * n[1] + FM[3 * s + 2] * n[2];
+            fnP[s] = FP[3 * s] * n[0] + FP[3 * s + 1] * n[1] + FP[3 * s + 2] * n[2];
+        }
+        const double SM = fmin(unM - cM, unP - cP), SP = fmax(unM + cM, unP + cP);
+        const double S0 = (pP - pM + rM * unM * (SM - unM) - rP * unP * (SP - unP)) /
+                          (rM * (SM - unM) - rP * (SP - unP));
+        const double p0 =
+            (pP + pM + rM * (SM - unM) * (S0 - unM) + rP * (SP - unP) * (S0 - unP)) / 2;
+        double mp = p0;
+        if constexpr (REF)
+            if (m.subtract) mp = p0 - (auxM[OREF + 1] + auxP[OREF + 1]) / 2;
+        const double pD[5] = {0.0, mp * n[0], mp * n[1], mp * n[2], p0 * S0};
+        if (0 <= SM) {
+#pragma unroll
+            for (int s = 0; s < 5; ++s) fluxn[s] += fnM[s];
+        } else if (0 <= S0) {
+#pragma unroll
+            for (int s = 0; s < 5; ++s)
+                fluxn[s] += (S0 * (SM * QM[s] - fnM[s]) + SM * pD[s]) / (SM - S0);
+        } else if (0 <= SP) {
+#pragma unroll
+            for (int s = 0; s < 5; ++s)
+                fluxn[s] += (S0 * (SP * QP[s] - fnP[s]) + SP * pD[s]) / (SP - S0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 5; ++s) fluxn[s] += fnP[s];
+        }
     }
     // DryModel atmos_nodal_update_auxiliary_state! (moisture.jl:53-62)
     __device__ static void update_aux(const Params &m, const double *Q, double *aux, double)

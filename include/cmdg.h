@@ -38,7 +38,12 @@ typedef enum cmdg_status {
 enum { CMDG_EVERY_DIRECTION = 0, CMDG_HORIZONTAL_DIRECTION = 1, CMDG_VERTICAL_DIRECTION = 2 };
 /* first-order numerical flux (NumericalFluxes.jl:219,298); second order and gradient
  * fluxes are the central ones (:668, :65), as in every configuration in scope */
-enum { CMDG_RUSANOV = 0, CMDG_CENTRAL_FIRST_ORDER = 1 };
+enum {
+    CMDG_RUSANOV = 0, CMDG_CENTRAL_FIRST_ORDER = 1,
+    /* methods the dry AtmosModel defines for itself (src/Atmos/Model/AtmosModel.jl:1006,
+     * :1154); CMDG_PHYSICS_DRY_ATMOS without orientation / reference state only */
+    CMDG_ROE = 2, CMDG_HLLC = 3
+};
 /* balance laws carried as device functors (pointwise Julia physics cannot cross a C ABI) */
 enum {
     CMDG_PHYSICS_ADVECTION_DIFFUSION = 1, CMDG_PHYSICS_DRY_ATMOS = 2,
@@ -64,7 +69,7 @@ typedef struct cmdg_desc {
     int32_t physics_id;          /* CMDG_PHYSICS_* */
     int32_t iparam[16];          /* law parameters, see csrc/physics_*.h */
     double dparam[64];
-    int32_t nf_first;            /* CMDG_RUSANOV | CMDG_CENTRAL_FIRST_ORDER */
+    int32_t nf_first;            /* CMDG_RUSANOV | CMDG_CENTRAL_FIRST_ORDER | CMDG_ROE | CMDG_HLLC */
     int32_t direction;           /* dg.direction */
     int32_t diffusion_direction; /* dg.diffusion_direction */
     int32_t stacked;             /* isstacked(grid.topology): with a vertical-only

@@ -220,6 +220,10 @@ static void nf_first_order(const orc_physics *ph, double *fluxn, const double *n
                            int facedir)
 {
     const int ns = ph->ns;
+    if (ph->nf_first >= ORC_NF_ROE) {  /* methods a law defines for itself */
+        ph->numerical_flux_law(ph->p, ph->nf_first, fluxn, n, QM, auxM, QP, auxP, t, facedir);
+        return;
+    }
     double FM[3 * ORC_MAXS], FP[3 * ORC_MAXS];
     fillnz(FM, 3 * ns);
     ph->flux_first_order(ph->p, FM, QM, auxM, t, facedir);

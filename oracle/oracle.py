@@ -46,7 +46,7 @@ class _Physics(C.Structure):
                     "gradient_flux", "post_gradient_laplacian", "wavespeed", "boundary_state",
                     "boundary_flux_second_order", "boundary_state_divergence",
                     "boundary_state_higher_order", "update_aux", "courant",
-                    "update_penalty")])
+                    "update_penalty", "numerical_flux_law")])
 
 
 class _Grid(C.Structure):
@@ -132,6 +132,8 @@ class OraclePhysics:
                 4: "orc_pgrad_new", 5: "orc_sw_new", 6: "orc_moist_new"}[law.physics_id]
         self.c = getattr(lib(), ctor)(_p(self._ip), _p(self._dp), int(nf_first))
         ph = self.c.contents
+        if nf_first >= 2 and not ph.numerical_flux_law:
+            raise ValueError("Roe / HLLC numerical fluxes are methods of the dry atmosphere law only")
         self.ns, self.naux, self.ngrad = ph.ns, ph.naux, ph.ngrad
         self.ngf, self.ngl, self.nhyp = ph.ngf, ph.ngl, ph.nhyp
         assert (self.ns, self.naux, self.ngrad, self.ngf, self.ngl, self.nhyp) == (

@@ -469,6 +469,85 @@ static double at_courant(const void *p_, int kind, const double *Q, const double
     return dt * (normu + ss) / dx;
 }
 
+/* RoeNumericalFlux (AtmosModel.jl:1003-1130, DryModel only) and HLLCNumericalFlux
+ * (:1154-1276) */
+static inline double roe_average(double sM, double sP, double vM, double vP)
+{
+    return (sM * vM + sP * vP) / (sM + sP);
+}
+static void at_nf_law(const void *p_, int nf, double *fluxn, const double *n, const double *QM,
+                      const double *auxM, const double *QP, const double *auxP, double t, int dir)
+{
+    const atmos_t *m = (const atmos_t *)p_;
+    double FM[15], FP[15], fnM[5], fnP[5];
+    for (int i = 0; i < 15; ++i) FM[i] = FP[i] = -0.0;
+    at_flux1(p_, FM, QM, auxM, t, dir);
+    at_flux1(p_, FP, QP, auxP, t, dir);
+    const double rM = QM[0], rP = QP[0];
+    double uM[3], uP[3];
+    for (int d = 0; d < 3; ++d) { uM[d] = QM[1 + d] / rM; uP[d] = QP[1 + d] / rP; }
+    const double TM = air_T(m, internal_energy(m, QM, auxM)), TP = air_T(m, internal_energy(m, QP, auxP));
+    const double pM = air_p(m, TM, rM), pP = air_p(m, TP, rP);
+    const double cM = soundspeed(m, TM), cP = soundspeed(m, TP);
+    const double unM = uM[0] * n[0] + uM[1] * n[1] + uM[2] * n[2];
+    const double unP = uP[0] * n[0] + uP[1] * n[1] + uP[2] * n[2];
+    if (nf == ORC_NF_ROE) {
+        /* central part (NumericalFluxes.jl:300-340) */
+        const double nh[3] = {n[0] / 2, n[1] / 2, n[2] / 2};
+        for (int s = 0; s < 5; ++s)
+            fluxn[s] += (FM[3 * s] + FP[3 * s]) * nh[0] + (FM[3 * s + 1] + FP[3 * s + 1]) * nh[1] +
+                        (FM[3 * s + 2] + FP[3 * s + 2]) * nh[2];
+        const double Phi = m->orient ? auxM[m->oPhi] : 0.0;
+        const double eM = QM[4] / rM, eP = QP[4] / rP;
+        /* total_specific_enthalpy(ts, e_tot) = e_tot + R_m T */
+        const double hM = m->zero_h ? 0.0 : eM + m->R_d * TM;
+        const double hP = m->zero_h ? 0.0 : eP + m->R_d * TP;
+        const double sM = sqrt(rM), sP = sqrt(rP);
+        const double rt = sqrt(rM * rP);
+        double ut[3], du[3];
+        for (int d = 0; d < 3; ++d) { ut[d] = roe_average(sM, sP, uM[d], uP[d]); du[d] = uP[d] - uM[d]; }
+        const double ht = roe_average(sM, sP, hM, hP);
+        const double ct = sqrt(roe_average(sM, sP, cM * cM, cP * cP));
+        const double utn = ut[0] * n[0] + ut[1] * n[1] + ut[2] * n[2];
+        const double dr = rP - rM, dp = pP - pM;
+        const double dun = du[0] * n[0] + du[1] * n[1] + du[2] * n[2];
+        const double w1 = fabs(utn - ct) * (dp - rt * ct * dun) / (2 * (ct * ct));
+        const double w2 = fabs(utn + ct) * (dp + rt * ct * dun) / (2 * (ct * ct));
+        const double w3 = fabs(utn) * (dr - dp / (ct * ct));
+        const double w4 = fabs(utn) * rt;
+        fluxn[0] -= (w1 + w2 + w3) / 2;
+        for (int d = 0; d < 3; ++d)
+            fluxn[1 + d] -= (w1 * (ut[d] - ct * n[d]) + w2 * (ut[d] + ct * n[d]) + w3 * ut[d] +
+                             w4 * (du[d] - dun * n[d])) / 2;
+        const double utut = ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2];
+        const double utdu = ut[0] * du[0] + ut[1] * du[1] + ut[2] * du[2];
+        fluxn[4] -= (w1 * (ht - ct * utn) + w2 * (ht + ct * utn) +
+                     w3 * (utut / 2 + Phi - m->T_0 * m->cv_d) + w4 * (utdu - utn * dun)) / 2;
+        return;
+    }
+    /* HLLC: flux' * n */
+    for (int s = 0; s < 5; ++s) {
+        fnM[s] = FM[3 * s] * n[0] + FM[3 * s + 1] * n[1] + FM[3 * s + 2] * n[2];
+        fnP[s] = FP[3 * s] * n[0] + FP[3 * s + 1] * n[1] + FP[3 * s + 2] * n[2];
+    }
+    const double SM = fmin(unM - cM, unP - cP), SP = fmax(unM + cM, unP + cP);
+    const double S0 = (pP - pM + rM * unM * (SM - unM) - rP * unP * (SP - unP)) /
+                      (rM * (SM - unM) - rP * (SP - unP));
+    const double p0 = (pP + pM + rM * (SM - unM) * (S0 - unM) + rP * (SP - unP) * (S0 - unP)) / 2;
+    double mp = p0;
+    if (m->ref && m->subtract) mp = p0 - (auxM[m->oRef + 1] + auxP[m->oRef + 1]) / 2;
+    const double pD[5] = {0.0, mp * n[0], mp * n[1], mp * n[2], p0 * S0};
+    if (0 <= SM) {
+        for (int s = 0; s < 5; ++s) fluxn[s] += fnM[s];
+    } else if (SM < 0 && 0 <= S0) {
+        for (int s = 0; s < 5; ++s) fluxn[s] += (S0 * (SM * QM[s] - fnM[s]) + SM * pD[s]) / (SM - S0);
+    } else if (S0 < 0 && 0 <= SP) {
+        for (int s = 0; s < 5; ++s) fluxn[s] += (S0 * (SP * QP[s] - fnP[s]) + SP * pD[s]) / (SP - S0);
+    } else {
+        for (int s = 0; s < 5; ++s) fluxn[s] += fnP[s];
+    }
+}
+
 orc_physics *orc_atmos_new(const int *ip, const double *dp, int nf_first)
 {
     orc_physics *ph = (orc_physics *)calloc(1, sizeof(orc_physics));
@@ -512,5 +591,6 @@ orc_physics *orc_atmos_new(const int *ip, const double *dp, int nf_first)
     ph->boundary_state_higher_order = at_bhigher;
     ph->update_aux = at_update_aux;
     ph->courant = at_courant;
+    ph->numerical_flux_law = at_nf_law;
     return ph;
 }

@@ -134,6 +134,9 @@ def test_fails_loudly_without_fallback(cm):
     law, grid, _ = pseudo1d_setup(Ne=2, N=8)         # compiled in: N = 1..7
     with pytest.raises(cm._lib.CmdgError):
         cm.dgmodel.DGModel(law, grid)
+    law, grid, _ = pseudo1d_setup(Ne=2, N=4)         # Roe / HLLC are methods of the dry atmosphere
+    with pytest.raises(cm._lib.CmdgError):
+        cm.dgmodel.DGModel(law, grid, numerical_flux_first_order=cm.balancelaws.RoeNumericalFlux)
 
 
 @pytest.mark.parametrize("direction", [0, 1, 2])
@@ -199,7 +202,7 @@ def test_local_multirank_hyperdiffusion(cm, oracle, torch):
         d.close()
 
 
-@pytest.mark.parametrize("nf,name", [(0, "Rusanov"), (1, "Central")])
+@pytest.mark.parametrize("nf,name", [(0, "Rusanov"), (1, "Central"), (2, "Roe"), (3, "HLLC")])
 def test_isentropic_vortex_gpu(cm, oracle, torch, nf, name):
     from helpers import isentropic_vortex_setup
     law, grid, dt, timeend, nsteps = isentropic_vortex_setup()
@@ -224,6 +227,26 @@ def test_isentropic_vortex_gpu(cm, oracle, torch, nf, name):
     err = dg.euclidean_distance(Q, dg.init_ode_state(timeend))
     g = GOLD["isentropicvortex"]
     exp = g["dim3"][name][0]
+    assert abs(err - exp) <= g["rtol"] * exp
+    dg.close()
+
+
+@pytest.mark.parametrize("level", [2, 3])
+@pytest.mark.parametrize("nf,name", [(0, "Rusanov"), (1, "Central"), (2, "Roe"), (3, "HLLC")])
+def test_isentropic_vortex_refinement_levels_gpu(cm, torch, nf, name, level):
+    """isentropicvortex.jl:60-110 tabulates the error after one domain crossing for four
+    refinement levels; levels 2 and 3 are run here on the device alone (level 1 above is
+    also checked against the oracle)."""
+    from helpers import isentropic_vortex_setup
+    law, grid, dt, timeend, nsteps = isentropic_vortex_setup(level=level)
+    dg = cm.dgmodel.DGModel(law, grid, numerical_flux_first_order=nf, direction=0)
+    Q = dg.init_ode_state(0.0)
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+    cm.odesolvers.solve(Q, solver, timeend=timeend)
+    assert solver.steps in (nsteps, nsteps + 1)
+    err = dg.euclidean_distance(Q, dg.init_ode_state(timeend))
+    g = GOLD["isentropicvortex"]
+    exp = g["dim3"][name][level - 1]
     assert abs(err - exp) <= g["rtol"] * exp
     dg.close()
 

@@ -112,11 +112,12 @@ def test_periodic_hyperdiffusion_level1(oracle, direction):
     assert abs(err - exp) <= g["rtol"] * exp, (err, exp)
 
 
-@pytest.mark.parametrize("nf,name", [(0, "Rusanov"), (1, "Central")])
+@pytest.mark.parametrize("nf,name", [(0, "Rusanov"), (1, "Central"), (2, "Roe"), (3, "HLLC")])
 def test_isentropic_vortex_level1(oracle, nf, name):
     """Dry Euler through the AtmosModel physics (pins the restated Thermodynamics.jl /
     CLIMAParameters.jl closed forms, Rusanov wavespeed and the 3-D periodic face-connected
-    BrickTopology) -- isentropicvortex.jl:105,109."""
+    BrickTopology) -- isentropicvortex.jl:105,109; Roe and HLLC (:115, :144) pin the law's
+    own numerical_flux_first_order! methods (AtmosModel.jl:1006, :1154)."""
     from helpers import isentropic_vortex_setup
     law, grid, dt, timeend, nsteps = isentropic_vortex_setup()
     dg = oracle.OracleDGModel(law, grid, nf_first=nf, direction=0)
