@@ -17,8 +17,8 @@ from .mesh.grids import _x1, _x2, _x3
 
 EveryDirection, HorizontalDirection, VerticalDirection = 0, 1, 2
 RusanovNumericalFlux, CentralNumericalFluxFirstOrder = 0, 1
-# methods of the dry AtmosModel (src/Atmos/Model/AtmosModel.jl:1006, :1154)
-RoeNumericalFlux, HLLCNumericalFlux = 2, 3
+# methods of the dry AtmosModel (src/Atmos/Model/AtmosModel.jl:1006, :1154, :1515)
+RoeNumericalFlux, HLLCNumericalFlux, LMARSNumericalFlux = 2, 3, 4
 
 PHYSICS_ADVECTION_DIFFUSION = 1
 PHYSICS_DRY_ATMOS = 2
@@ -30,7 +30,7 @@ PHYSICS_MOIST_ATMOS = 6
 __all__ = [
     "EveryDirection", "HorizontalDirection", "VerticalDirection",
     "RusanovNumericalFlux", "CentralNumericalFluxFirstOrder", "RoeNumericalFlux",
-    "HLLCNumericalFlux",
+    "HLLCNumericalFlux", "LMARSNumericalFlux",
     "InhomogeneousBC", "HomogeneousBC", "AdvectionDiffusion", "Pseudo1D",
     "ConstantHyperDiffusion", "DirectionSplitBox",
 ]

@@ -910,12 +910,12 @@ int cmdg_create(const cmdg_desc *d, cmdg_handle *out)
         g_create_err = "only dim == 3 with one horizontal polynomial order is compiled in";
         return CMDG_ERR_UNSUPPORTED;
     }
-    if (d->nf_first < CMDG_RUSANOV || d->nf_first > CMDG_HLLC) {
+    if (d->nf_first < CMDG_RUSANOV || d->nf_first > CMDG_LMARS) {
         g_create_err = "unknown first-order numerical flux";
         return CMDG_ERR_INVALID;
     }
     if (d->nf_first >= CMDG_ROE && d->physics_id != CMDG_PHYSICS_DRY_ATMOS) {
-        g_create_err = "Roe / HLLC numerical fluxes are methods of the dry atmosphere law only";
+        g_create_err = "Roe / HLLC / LMARS numerical fluxes are methods of the dry atmosphere law only";
         return CMDG_ERR_UNSUPPORTED;
     }
     std::string err;

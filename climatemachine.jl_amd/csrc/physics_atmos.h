@@ -514,8 +514,8 @@ struct DryAtmos {
 #pragma unroll
         for (int s = 0; s < 5; ++s) ws[s] = uN + ss;
     }
-    // RoeNumericalFlux (AtmosModel.jl:1003-1130, DryModel only) and HLLCNumericalFlux
-    // (:1154-1276); adds the normal flux to fluxn
+    // RoeNumericalFlux (AtmosModel.jl:1003-1130, DryModel only), HLLCNumericalFlux
+    // (:1154-1276) and LMARSNumericalFlux (:1515-1600); adds the normal flux to fluxn
     __device__ static double roe_average(double sM, double sP, double vM, double vP)
     {
         return (sM * vM + sP * vP) / (sM + sP);
@@ -543,6 +543,27 @@ struct DryAtmos {
         const double cM = soundspeed(m, TM), cP = soundspeed(m, TP);
         const double unM = uM[0] * n[0] + uM[1] * n[1] + uM[2] * n[2];
         const double unP = uP[0] * n[0] + uP[1] * n[1] + uP[2] * n[2];
+        if (nf == NF_LMARS) {  // AtmosModel.jl:1515-1600, beta = 1
+            double ppM = pM, ppP = pP;
+            if constexpr (REF)
+                if (m.subtract) {
+                    ppM -= auxM[OREF + 1];
+                    ppP -= auxP[OREF + 1];
+                }
+            const double hM = m.zero_h ? 0.0 : QM[4] / rM + m.R_d * TM;
+            const double hP = m.zero_h ? 0.0 : QP[4] / rP + m.R_d * TP;
+            const double beta = 1.0;
+            const double u_half = 1.0 / 2 * (unP + unM) - beta * 1 / (rM + rP) / cM * (ppP - ppM);
+            const double p_half =
+                1.0 / 2 * (ppP + ppM) - beta * ((rM + rP) * cM) / 4 * (unP - unM);
+            const bool up = u_half > 0;
+            fluxn[0] += (up ? rM : rP) * u_half;
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                fluxn[1 + d] += (up ? QM[1 + d] : QP[1 + d]) * u_half + p_half * n[d];
+            fluxn[4] += (up ? rM * hM : rP * hP) * u_half;
+            return;
+        }
         if (nf == NF_ROE) {
             const double nh0 = n[0] / 2, nh1 = n[1] / 2, nh2 = n[2] / 2;
 #pragma unroll

@@ -41,8 +41,8 @@ enum { CMDG_EVERY_DIRECTION = 0, CMDG_HORIZONTAL_DIRECTION = 1, CMDG_VERTICAL_DI
 enum {
     CMDG_RUSANOV = 0, CMDG_CENTRAL_FIRST_ORDER = 1,
     /* methods the dry AtmosModel defines for itself (src/Atmos/Model/AtmosModel.jl:1006,
-     * :1154); CMDG_PHYSICS_DRY_ATMOS without orientation / reference state only */
-    CMDG_ROE = 2, CMDG_HLLC = 3
+     * :1154, :1515); CMDG_PHYSICS_DRY_ATMOS without orientation / reference state only */
+    CMDG_ROE = 2, CMDG_HLLC = 3, CMDG_LMARS = 4
 };
 /* balance laws carried as device functors (pointwise Julia physics cannot cross a C ABI) */
 enum {
@@ -69,7 +69,7 @@ typedef struct cmdg_desc {
     int32_t physics_id;          /* CMDG_PHYSICS_* */
     int32_t iparam[16];          /* law parameters, see csrc/physics_*.h */
     double dparam[64];
-    int32_t nf_first;            /* CMDG_RUSANOV | CMDG_CENTRAL_FIRST_ORDER | CMDG_ROE | CMDG_HLLC */
+    int32_t nf_first;            /* CMDG_RUSANOV | CMDG_CENTRAL_FIRST_ORDER | CMDG_ROE | CMDG_HLLC | CMDG_LMARS */
     int32_t direction;           /* dg.direction */
     int32_t diffusion_direction; /* dg.diffusion_direction */
     int32_t stacked;             /* isstacked(grid.topology): with a vertical-only

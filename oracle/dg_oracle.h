@@ -20,7 +20,7 @@
 #define ORC_MAXS 32 /* max vars of any one state type held in a local array */
 
 enum { ORC_EVERY = 0, ORC_HORIZONTAL = 1, ORC_VERTICAL = 2 };
-enum { ORC_NF_RUSANOV = 0, ORC_NF_CENTRAL = 1, ORC_NF_ROE = 2, ORC_NF_HLLC = 3 };
+enum { ORC_NF_RUSANOV = 0, ORC_NF_CENTRAL = 1, ORC_NF_ROE = 2, ORC_NF_HLLC = 3, ORC_NF_LMARS = 4 };
 /* which numerical flux asks for the boundary state (dispatch of boundary_state!) */
 enum { ORC_BS_FIRST = 0, ORC_BS_GRADIENT = 1 };
 
@@ -71,8 +71,8 @@ typedef struct orc_physics {
      * (NumericalFluxes.jl:222, 266-279); NULL = the default no-op */
     void (*update_penalty)(const void *p, double *penalty, const double *n, const double *QM,
                            const double *QP);
-    /* law-specific numerical_flux_first_order! methods (ORC_NF_ROE, ORC_NF_HLLC:
-     * src/Atmos/Model/AtmosModel.jl:1006-1130, :1154-1276); adds the normal flux to fluxn */
+    /* law-specific numerical_flux_first_order! methods (ORC_NF_ROE, ORC_NF_HLLC,
+     * ORC_NF_LMARS: src/Atmos/Model/AtmosModel.jl:1006-1130, :1154-1276, :1515-1600); adds the normal flux to fluxn */
     void (*numerical_flux_law)(const void *p, int nf, double *fluxn, const double *n,
                                const double *QM, const double *auxM, const double *QP,
                                const double *auxP, double t, int facedir);

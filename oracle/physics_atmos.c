@@ -469,8 +469,8 @@ static double at_courant(const void *p_, int kind, const double *Q, const double
     return dt * (normu + ss) / dx;
 }
 
-/* RoeNumericalFlux (AtmosModel.jl:1003-1130, DryModel only) and HLLCNumericalFlux
- * (:1154-1276) */
+/* RoeNumericalFlux (AtmosModel.jl:1003-1130, DryModel only), HLLCNumericalFlux
+ * (:1154-1276) and LMARSNumericalFlux (:1515-1600) */
 static inline double roe_average(double sM, double sP, double vM, double vP)
 {
     return (sM * vM + sP * vP) / (sM + sP);
@@ -491,6 +491,20 @@ static void at_nf_law(const void *p_, int nf, double *fluxn, const double *n, co
     const double cM = soundspeed(m, TM), cP = soundspeed(m, TP);
     const double unM = uM[0] * n[0] + uM[1] * n[1] + uM[2] * n[2];
     const double unP = uP[0] * n[0] + uP[1] * n[1] + uP[2] * n[2];
+    if (nf == ORC_NF_LMARS) { /* AtmosModel.jl:1515-1600, beta = 1 */
+        double ppM = pM, ppP = pP;
+        if (m->ref && m->subtract) { ppM -= auxM[m->oRef + 1]; ppP -= auxP[m->oRef + 1]; }
+        const double hM = m->zero_h ? 0.0 : QM[4] / rM + m->R_d * TM;
+        const double hP = m->zero_h ? 0.0 : QP[4] / rP + m->R_d * TP;
+        const double beta = 1.0;
+        const double u_half = 1.0 / 2 * (unP + unM) - beta * 1 / (rM + rP) / cM * (ppP - ppM);
+        const double p_half = 1.0 / 2 * (ppP + ppM) - beta * ((rM + rP) * cM) / 4 * (unP - unM);
+        const int up = u_half > 0;
+        fluxn[0] += (up ? rM : rP) * u_half;
+        for (int d = 0; d < 3; ++d) fluxn[1 + d] += (up ? QM[1 + d] : QP[1 + d]) * u_half + p_half * n[d];
+        fluxn[4] += (up ? rM * hM : rP * hP) * u_half;
+        return;
+    }
     if (nf == ORC_NF_ROE) {
         /* central part (NumericalFluxes.jl:300-340) */
         const double nh[3] = {n[0] / 2, n[1] / 2, n[2] / 2};

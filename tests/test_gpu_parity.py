@@ -231,6 +231,36 @@ def test_isentropic_vortex_gpu(cm, oracle, torch, nf, name):
     dg.close()
 
 
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_isentropic_vortex_lmars_gpu(cm, oracle, torch, level):
+    """isentropicvortex_lmars.jl:58-82 (dims = 3): norm(Q) / norm(Q0) == 1 to rtol 1e-5 with the
+    LMARS flux; at level 1 the tendency is also compared with the oracle's."""
+    from helpers import isentropic_vortex_setup
+    law, grid, dt, timeend, nsteps = isentropic_vortex_setup(level=level)
+    nr = grid.nreal
+    dg = cm.dgmodel.DGModel(law, grid, direction=0,
+                            numerical_flux_first_order=cm.balancelaws.LMARSNumericalFlux)
+    Q = dg.init_ode_state(0.0)
+    if level == 1:
+        odg = oracle.OracleDGModel(law, grid, nf_first=4, direction=0)
+        Q0 = Q.cpu().numpy()
+        To = np.zeros_like(Q0)
+        odg(To, Q0.copy(), 0.0, 1.0, 0.0)
+        Tg = dg.create_state()
+        dg(Tg, Q, 0.0, 1.0, 0.0)
+        Tg = Tg.cpu().numpy()
+        for s in range(5):
+            assert rel_linf(Tg[:nr, s], To[:nr, s]) < TOL
+    eng0 = dg.norm(Q)
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+    cm.odesolvers.solve(Q, solver, timeend=timeend)
+    engf = dg.norm(Q)
+    assert abs(engf / eng0 - 1.0) <= 1e-5
+    err = dg.euclidean_distance(Q, dg.init_ode_state(timeend))
+    assert err < 1.5 * GOLD["isentropicvortex"]["dim3"]["Rusanov"][level - 1]
+    dg.close()
+
+
 @pytest.mark.parametrize("level", [2, 3])
 @pytest.mark.parametrize("nf,name", [(0, "Rusanov"), (1, "Central"), (2, "Roe"), (3, "HLLC")])
 def test_isentropic_vortex_refinement_levels_gpu(cm, torch, nf, name, level):

@@ -131,6 +131,25 @@ def test_isentropic_vortex_level1(oracle, nf, name):
 
 
 @pytest.mark.parametrize("level", [1, 2])
+def test_isentropic_vortex_lmars(oracle, level):
+    """isentropicvortex_lmars.jl:58-82 (dims = 3): with the LMARS flux the test's criterion is
+    norm(Q) / norm(Q0) == 1 to rtol 1e-5 after one domain crossing."""
+    from helpers import isentropic_vortex_setup
+    law, grid, dt, timeend, nsteps = isentropic_vortex_setup(level=level)
+    dg = oracle.OracleDGModel(law, grid, nf_first=4, direction=0)
+    Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
+    zero = np.zeros_like(Q)
+    eng0 = np.sqrt(oracle.weighted_norm2_local(grid, Q, zero))
+    oracle.solve(dg, Q, dt, timeend)
+    engf = np.sqrt(oracle.weighted_norm2_local(grid, Q, zero))
+    assert abs(engf / eng0 - 1.0) <= 1e-5
+    # and the flow is still the vortex: error of the order of the Roe / HLLC ones
+    Qe = law.init_state_prognostic(grid, dg.state_auxiliary, timeend)
+    err = np.sqrt(oracle.weighted_norm2_local(grid, Q, Qe))
+    assert err < 1.5 * GOLD["isentropicvortex"]["dim3"]["Rusanov"][level - 1]
+
+
+@pytest.mark.parametrize("level", [1, 2])
 def test_hyperdiffusion_with_boundary_data(oracle, level):
     """hyperdiffusion_bc.jl (dim = 3): boundary data of orders 0-3 on six differently tagged
     faces; pins the boundary branches of the divergence, higher-order and second-order
