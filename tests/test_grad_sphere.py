@@ -34,3 +34,24 @@ def test_grad_sphere_matches_reference(level):
     g = G.auxiliary_field_gradient(grid, a, 1)
     err = np.sqrt((Mw[:, None, :] * g ** 2)[:grid.nreal].sum())
     assert err < GOLD["horizontal_atol"]
+
+
+@pytest.mark.parametrize("direction", [0, 1, 2])
+def test_grad_brick_is_exact_for_the_test_polynomial(direction):
+    """test/Numerics/DGMethods/grad_test.jl:33-47, 121-150 (dim = 3, polynomial order (4,4),
+    5^3 elements on [0,3]^3): a = x^2 + y^3 + z^2 y^2 - x y z is in the N = 4 space, so the
+    element-local gradient equals the analytic one in the test's `isapprox` sense
+    (norm(g - exact) <= sqrt(eps) * norm(exact)); the components a direction leaves out are zero."""
+    rng = [np.linspace(0.0, 3.0, 6)] * 3
+    topl = M.StackedBrickTopology(rng, periodicity=(False,) * 3, connectivity="full")
+    grid = M.DiscontinuousSpectralElementGrid(topl, 4)
+    G = M.grids
+    x, y, z = (grid.vgeo[:, c, :] for c in (G._x1, G._x2, G._x3))
+    a = x ** 2 + y ** 3 + z ** 2 * y ** 2 - x * y * z
+    gx, gy, gz = 2 * x - y * z, 3 * y ** 2 + 2 * z ** 2 * y - x * z, 2 * z * y ** 2 - x * y
+    zero = np.zeros_like(x)
+    exact = {0: (gx, gy, gz), 1: (gx, gy, zero), 2: (zero, zero, gz)}[direction]
+    exact = np.stack(exact, axis=1)
+    g = G.auxiliary_field_gradient(grid, a, direction)
+    assert np.linalg.norm(g - exact) <= np.sqrt(np.finfo(float).eps) * np.linalg.norm(exact)
+    assert np.linalg.norm(g - exact) <= 1e-11 * np.linalg.norm(exact)
