@@ -71,3 +71,28 @@ def test_courant_on_the_sphere_uses_the_radial_direction(oracle):
     dxv = M.grids.min_node_distance(grid, VERT)
     assert ch < 1e-3 * cv          # grad(Phi) is a DG gradient: radial to discretisation error
     assert cv == pytest.approx(3.0 / dxv, rel=2e-2)     # coarse sphere: |grad Phi| / g = 1 +- 0.5 %
+
+
+def test_min_node_distance_on_the_reference_stretched_brick():
+    """test/Numerics/Mesh/min_node_distance.jl:18-79 (dim = 3, N = 4, Float64): 10 x 10 x 4
+    stacked brick whose upper half is stretched by two in each direction, so the smallest
+    node spacings are those of the unstretched elements: dxi / (2 Neh) and dxi / (2 Nev)."""
+    Neh, Nev, N = 10, 4, 4
+    rng = [np.linspace(0.0, 1.0, Neh + 1), np.linspace(0.0, 1.0, Neh + 1),
+           np.linspace(1.0, 2.0, Nev + 1)]
+    topl = M.StackedBrickTopology(rng, periodicity=(False,) * 3)
+
+    def warp(a, b, c):
+        a = np.where(a >= 0.5, 0.5 + 2 * (a - 0.5), a)
+        b = np.where(b >= 0.5, 0.5 + 2 * (b - 0.5), b)
+        c = np.where(c >= 1.5, 1.5 + 2 * (c - 1.5), c)
+        return a, b, c
+    grid = M.DiscontinuousSpectralElementGrid(topl, N, meshwarp=warp)
+    xi = M.elements.lglpoints(N)[0]
+    dxi = xi[1] - xi[0]
+    hmnd, vmnd = dxi / (2 * Neh), dxi / (2 * Nev)
+    rel = np.sqrt(np.finfo(float).eps)          # the test's `isapprox`
+    assert M.grids.min_node_distance(grid, 0) == pytest.approx(hmnd, rel=rel)
+    assert M.grids.min_node_distance(grid, VERT) == pytest.approx(vmnd, rel=rel)
+    assert M.grids.min_node_distance(grid, HORZ) == pytest.approx(hmnd, rel=rel)
+    assert M.grids.min_node_distance(grid, HORZ) == pytest.approx(hmnd, rel=1e-13)

@@ -227,3 +227,54 @@ def test_partition_covers_everything_once(size):
         seen += list(t.globalelems[:t.nreal])
         assert len(t.interiorelems) + len(t.exteriorelems) == t.nreal
     assert sorted(seen) == list(range(1, 6 * 9 * 2 + 1))
+
+
+@pytest.mark.parametrize("N", [(2, 2, 2), (2, 3, 4), (4, 3, 2)])
+def test_metric_terms_of_two_affine_elements(N):
+    """test/Numerics/Mesh/Metrics.jl:560-690 ("3-D Metric terms", linear test, Float64): two
+    2 x 2 x 2 cubes, the second rotated by a quarter turn about x3, with a different polynomial
+    order per direction: coordinates, mass, the nine metric terms, surface mass and normals."""
+    G = M.grids
+    Nq = [n + 1 for n in N]
+    xw = [M.elements.lglpoints(n) for n in N]
+    xi, om = [p[0] for p in xw], [p[1] for p in xw]
+    D = [M.elements.spectralderivative(x) for x in xi]
+    e2c = np.zeros((2, 8, 3))
+    e2c[0] = np.array([[0, 2, 0, 2, 0, 2, 0, 2], [0, 0, 2, 2, 0, 0, 2, 2],
+                       [0, 0, 0, 0, 2, 2, 2, 2]]).T
+    e2c[1] = np.array([[2, 2, 0, 0, 2, 2, 0, 0], [0, 2, 0, 2, 0, 2, 0, 2],
+                       [0, 0, 0, 0, 2, 2, 2, 2]]).T
+    vgeo, sgeo = G.computegeometry(e2c, D, xi, om)
+    col = lambda c: vgeo[:, c, :].reshape(2, Nq[2], Nq[1], Nq[0])   # (e, k, j, i)
+    r1, r2, r3 = xi[0][None, None, :], xi[1][None, :, None], xi[2][:, None, None]
+    one = np.ones((Nq[2], Nq[1], Nq[0]))
+    tol = dict(rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(col(G._x1)[0], (1 + r1) * one, **tol)
+    np.testing.assert_allclose(col(G._x1)[1], (1 - r2) * one, **tol)
+    np.testing.assert_allclose(col(G._x2)[0], (1 + r2) * one, **tol)
+    np.testing.assert_allclose(col(G._x2)[1], (1 + r1) * one, **tol)
+    for e in range(2):
+        np.testing.assert_allclose(col(G._x3)[e], (1 + r3) * one, **tol)
+        np.testing.assert_allclose(col(G._M)[e],
+                                   om[2][:, None, None] * om[1][None, :, None] * om[0][None, None, :],
+                                   **tol)
+    exact = {G._xi1x1: (1, 0), G._xi1x2: (0, 1), G._xi2x1: (0, -1), G._xi2x2: (1, 0),
+             G._xi3x3: (1, 1), G._xi1x3: (0, 0), G._xi2x3: (0, 0), G._xi3x1: (0, 0),
+             G._xi3x2: (0, 0)}
+    for c, (a, b) in exact.items():
+        assert np.abs(col(c)[0] - a).max() <= 100 * np.finfo(float).eps
+        assert np.abs(col(c)[1] - b).max() <= 100 * np.finfo(float).eps
+    normals = np.zeros((2, 6, 3))
+    normals[0, 0, 0], normals[0, 1, 0], normals[1, 2, 0], normals[1, 3, 0] = -1, 1, 1, -1
+    normals[0, 2, 1], normals[0, 3, 1], normals[1, 0, 1], normals[1, 1, 1] = -1, 1, -1, 1
+    normals[:, 4, 2], normals[:, 5, 2] = -1, 1
+    Np = int(np.prod(Nq))
+    for d in range(3):
+        others = [j for j in range(3) if j != d]
+        Mf = np.kron(om[others[1]], om[others[0]])          # lower direction fastest
+        nfp = Np // Nq[d]
+        for f in (2 * d, 2 * d + 1):
+            for e in range(2):
+                np.testing.assert_allclose(sgeo[e, f, :nfp, G._sM], Mf, **tol)
+                for c, k in enumerate((G._n1, G._n2, G._n3)):
+                    np.testing.assert_allclose(sgeo[e, f, :nfp, k], normals[e, f, c], **tol)
