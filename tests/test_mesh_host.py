@@ -278,3 +278,46 @@ def test_metric_terms_of_two_affine_elements(N):
                 np.testing.assert_allclose(sgeo[e, f, :nfp, G._sM], Mf, **tol)
                 for c, k in enumerate((G._n1, G._n2, G._n3)):
                     np.testing.assert_allclose(sgeo[e, f, :nfp, k], normals[e, f, c], **tol)
+
+
+def _check_rank_tables(t, fx, rk, nface=4):
+    ex = fx["ranks"][rk]
+    ge = np.array(ex["globalelems"]) - 1
+    nr = ex["nrealelem"]
+    assert t.nreal == nr and t.nelem == len(ge)
+    assert np.array_equal(np.asarray(t.elemtoelem).T, np.array(ex["elemtoelem"]))
+    gf = np.array(fx["globalelemtoface"])
+    assert np.array_equal(np.asarray(t.elemtoface).T[:, :nr], gf[:, ge[:nr]])
+    gb = np.array(fx.get("globalelemtobndy", np.zeros_like(gf)))
+    assert np.array_equal(np.asarray(t.elemtobndy).T, gb[:, ge])
+    assert np.all(np.asarray(t.elemtoordr) == 1)
+    assert list(t.nabrtorank) == ex["nabrtorank"]
+    assert [list(r) for r in t.nabrtorecv] == ex["nabrtorecv"]
+    assert [list(r) for r in t.nabrtosend] == ex["nabrtosend"]
+    real = np.arange(1, nr + 1)
+    assert np.array_equal(np.sort(np.union1d(t.exteriorelems, t.interiorelems)), real)
+    assert np.array_equal(np.unique(t.sendelems), np.asarray(t.exteriorelems))
+    assert len(np.intersect1d(t.exteriorelems, t.interiorelems)) == 0
+    return ge
+
+
+@pytest.mark.parametrize("rk", [0, 1])
+def test_two_rank_periodic_brick_tables(rk):
+    """test/Numerics/Mesh/mpi_connect_ell.jl: 3 x 2 doubly periodic 2-D brick on two ranks."""
+    fx = json.load(open(os.path.join(GOLD, "mesh_connect.json")))["mpi_connect_ell"]
+    t = M.BrickTopology([np.linspace(0, 1, 4), np.linspace(0, 1, 3)], periodicity=(True, True),
+                        boundary=((1, 2), (3, 4)), connectivity="face", rank=rk, size=2)
+    _check_rank_tables(t, fx, rk)
+
+
+@pytest.mark.parametrize("rk", [0, 1, 2])
+def test_three_rank_stacked_brick_tables(rk):
+    """test/Numerics/Mesh/mpi_connect_stacked.jl: 3 x 2 stacked 2-D brick, periodic in the
+    stacking direction, on three ranks (whole columns per rank)."""
+    fx = json.load(open(os.path.join(GOLD, "mesh_connect.json")))["mpi_connect_stacked"]
+    t = M.StackedBrickTopology([np.arange(2, 6), np.arange(4, 7)], periodicity=(False, True),
+                               boundary=((1, 2), (3, 4)), connectivity="face", rank=rk, size=3)
+    ge = _check_rank_tables(t, fx, rk)
+    gc = np.array(fx["globalelemtocoord"])             # (elem, dim, vertex)
+    ec = np.asarray(t.elemtocoord)                     # (elem, vertex, dim)
+    assert np.array_equal(ec[:, :, :2].transpose(0, 2, 1), gc[ge])
