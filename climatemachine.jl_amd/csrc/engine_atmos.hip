@@ -31,9 +31,11 @@ static EngineBase *pick(const cmdg_desc *d, std::string &err)
         if constexpr (NQ == 5) {
             if (!orient && !ref && !hyp && d->iparam[14] == 0 && !mms)
                 return make_engine<DryAtmos<false, false, false, false, true>, NQ>(d);
+            if (orient && ref && !hyp && d->iparam[14] == 0)
+                return make_engine<DryAtmos<true, true, false, false, true>, NQ>(d);
         }
-        err = "DryAtmos: Roe / HLLC numerical fluxes are compiled for N = 4, NoOrientation, "
-              "NoReferenceState, constant viscosity";
+        err = "DryAtmos: Roe / HLLC / LMARS numerical fluxes are compiled for N = 4, constant "
+              "viscosity, without orientation and reference state or with both";
         return nullptr;
     }
     if (d->iparam[14] == 1) {  // SmagorinskyLilly (AtmosLES configurations)

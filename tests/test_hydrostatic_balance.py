@@ -1,7 +1,7 @@
 """Discrete hydrostatic balance of the reference state (src/Atmos/Model/ref_state.jl:150-175:
 rho_ref from the DG gradient of p_ref) -- test/Atmos/Model/discrete_hydrostatic_balance.jl:
-a state initialised to the reference state is steady to 100 eps over 100 s (central flux,
-LSRK54 at Courant number 0.1), in the LES box and on the GCM sphere, for the isothermal and the
+a state initialised to the reference state is steady to 100 eps over 100 s (central, Roe and
+HLLC fluxes, LSRK54 at Courant number 0.1), in the LES box and on the GCM sphere, for the isothermal and the
 decaying temperature profile.  CPU tests use the oracle; the ``gpu`` ones libcmdg, including
 the device-side evaluation of the PressureGradientModel."""
 import numpy as np
@@ -46,11 +46,12 @@ def balanced_setup(config, profile, balance=True, rank=0, size=1):
     return law, grid
 
 
+@pytest.mark.parametrize("nf", [1, 2, 3])      # Central, Roe, HLLC (:97-101)
 @pytest.mark.parametrize("profile", ["isothermal", "decaying"])
 @pytest.mark.parametrize("config", ["LES", "GCM"])
-def test_balanced_state_is_steady_oracle(oracle, config, profile):
+def test_balanced_state_is_steady_oracle(oracle, config, profile, nf):
     law, grid = balanced_setup(config, profile)
-    dg = oracle.OracleDGModel(law, grid, nf_first=1, direction=0, diffusion_direction=1)
+    dg = oracle.OracleDGModel(law, grid, nf_first=nf, direction=0, diffusion_direction=1)
     Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
     Q0 = Q.copy()
     T = np.zeros_like(Q)
@@ -75,14 +76,15 @@ def test_rebalanced_density_is_close_to_the_analytic_one(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nf", [1, 2, 3])      # Central, Roe, HLLC (:97-101)
 @pytest.mark.parametrize("config,profile", [("LES", "decaying"), ("GCM", "isothermal"),
                                             ("GCM", "decaying")])
-def test_balanced_state_is_steady_gpu(oracle, config, profile):
+def test_balanced_state_is_steady_gpu(oracle, config, profile, nf):
     import torch
     law, grid = balanced_setup(config, profile)
-    dg = cm.dgmodel.DGModel(law, grid, numerical_flux_first_order=1, direction=0,
+    dg = cm.dgmodel.DGModel(law, grid, numerical_flux_first_order=nf, direction=0,
                             diffusion_direction=1)
-    odg = oracle.OracleDGModel(law, grid, nf_first=1, direction=0, diffusion_direction=1)
+    odg = oracle.OracleDGModel(law, grid, nf_first=nf, direction=0, diffusion_direction=1)
     # device-side PressureGradientModel == oracle's
     aux = dg.state_auxiliary.cpu().numpy()
     o = law.off_ref
