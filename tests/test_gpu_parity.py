@@ -261,11 +261,11 @@ def test_isentropic_vortex_lmars_gpu(cm, oracle, torch, level):
     dg.close()
 
 
-@pytest.mark.parametrize("level", [2, 3])
+@pytest.mark.parametrize("level", [2, 3, 4])
 @pytest.mark.parametrize("nf,name", [(0, "Rusanov"), (1, "Central"), (2, "Roe"), (3, "HLLC")])
 def test_isentropic_vortex_refinement_levels_gpu(cm, torch, nf, name, level):
     """isentropicvortex.jl:60-110 tabulates the error after one domain crossing for four
-    refinement levels; levels 2 and 3 are run here on the device alone (level 1 above is
+    refinement levels; levels 2 to 4 are run here on the device alone (level 1 above is
     also checked against the oracle)."""
     from helpers import isentropic_vortex_setup
     law, grid, dt, timeend, nsteps = isentropic_vortex_setup(level=level)

@@ -321,3 +321,25 @@ def test_three_rank_stacked_brick_tables(rk):
     gc = np.array(fx["globalelemtocoord"])             # (elem, dim, vertex)
     ec = np.asarray(t.elemtocoord)                     # (elem, vertex, dim)
     assert np.array_equal(ec[:, :, :2].transpose(0, 2, 1), gc[ge])
+
+
+def test_hilbert_partition_of_the_reference_brick():
+    """test/Numerics/Mesh/mpi_partition.jl:14-92: the 4 x 4 brick (0:4, 5:9) on three ranks;
+    each rank's elements in space-filling-curve order (lower-left corners of `etc`) and the
+    boundary tags of the non-periodic direction (`etb`)."""
+    corners = [[(0, 5), (1, 5), (1, 6), (0, 6), (0, 7)],
+               [(0, 8), (1, 8), (1, 7), (2, 7), (2, 8)],
+               [(3, 8), (3, 7), (3, 6), (2, 6), (2, 5), (3, 5)]]
+    etb = [[[1, 0, 0, 1, 1], [0] * 5], [[1, 0, 0, 0, 0], [0] * 5],
+           [[0] * 6, [2, 2, 2, 0, 0, 2]]]
+    for rk in range(3):
+        t = M.BrickTopology([np.arange(0, 5), np.arange(5, 10)], periodicity=(False, True),
+                            boundary=((1, 2), (3, 4)), connectivity="face", rank=rk, size=3)
+        nr = t.nreal
+        ec = np.asarray(t.elemtocoord)[:nr]
+        assert [tuple(int(v) for v in ec[e, 0, :2]) for e in range(nr)] == corners[rk]
+        for e in range(nr):                      # vertex order: x fastest (etc[:, :, e])
+            x0, y0 = corners[rk][e]
+            assert ec[e, :, :2].tolist() == [[x0, y0], [x0 + 1, y0], [x0, y0 + 1], [x0 + 1, y0 + 1]]
+        assert np.asarray(t.elemtobndy)[:nr, :2].T.tolist() == etb[rk]
+        assert np.all(np.asarray(t.elemtobndy)[:nr, 2:] == 0)
