@@ -28,7 +28,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_workload(cm, name, rank, size, ne, args):
+def build_workload(cm, name, rank, size, ne, args, nhorz=None, nvert=None):
     """Returns (law, grid, direction, dt, description)."""
     M, BL = cm.mesh, cm.balancelaws
     if name == "advdiff-brick":
@@ -51,13 +51,15 @@ def build_workload(cm, name, rank, size, ne, args):
     if name == "heldsuarez":
         # BASELINE.json configs[2]: Held-Suarez dry GCM on the stacked cubed sphere, N = 4,
         # 8 levels, radii [a, a + 30 km] (experiments/AtmosGCM/heldsuarez.jl:174-240,
-        # src/Driver/driver_configs.jl:344-470).  Weak scaling keeps ~5 400 elements per GPU:
-        # n_horz = 11 / 15 / 21 / 30 at 1 / 2 / 4 / 8 GPUs (6 x 30 x 30 x 8 at 8 GPUs).
+        # src/Driver/driver_configs.jl:344-470).  One GPU runs the configuration the metric is
+        # quoted on, 6 x 30 x 30 x 8 = 43 200 elements.  --scaling weak (default) keeps that
+        # work per GPU: n_horz = 30 / 42 / 60 / 85 at 1 / 2 / 4 / 8 GPUs; --scaling strong
+        # keeps the 43 200-element sphere and splits it; --scaling weak-small is the round-1
+        # family of ~5 400 elements per GPU (n_horz = 11 / 15 / 21 / 30).
         A = cm.atmos
         ps = A.PlanetParameters()
-        n_horz = args.nhorz or {1: 11, 2: 15, 3: 18, 4: 21, 5: 24, 6: 26, 7: 28, 8: 30}.get(
-            size, int(round(30 * (size / 8) ** 0.5)))
-        n_vert = args.nvert
+        n_horz = nhorz or args.nhorz or hs_nhorz(args.scaling, size)
+        n_vert = nvert or args.nvert
         Rrange = np.linspace(ps.planet_radius, ps.planet_radius + 30e3, n_vert + 1)
         topl = M.StackedCubedSphereTopology(n_horz, Rrange, boundary=(1, 2), rank=rank, size=size)
         grid = M.DiscontinuousSpectralElementGrid(topl, 4,
@@ -126,6 +128,16 @@ def build_workload(cm, name, rank, size, ne, args):
     raise SystemExit("unknown workload %s" % name)
 
 
+def hs_nhorz(scaling, size):
+    if scaling == "strong":
+        return 30
+    if scaling == "weak-small":
+        return {1: 11, 2: 15, 3: 18, 4: 21, 5: 24, 6: 26, 7: 28, 8: 30}.get(
+            size, int(round(30 * (size / 8) ** 0.5)))
+    return {1: 30, 2: 42, 3: 52, 4: 60, 5: 67, 6: 73, 7: 79, 8: 85}.get(
+        size, int(round(30 * size ** 0.5)))
+
+
 def algorithmic_bytes_per_node(law, kernel, Nq=5):
     """SURVEY.md section 8(d): every distinct array element a pass needs moves once;
     face tables add F = (5*8 + 2*8) * 6 * Nfp / Np = 336 / Nq B per node (67 at N = 4)."""
@@ -142,28 +154,115 @@ def algorithmic_bytes_per_node(law, kernel, Nq=5):
     raise KeyError(kernel)
 
 
-def cpu_baseline(law, grid, direction, dt, budget_s):
-    """The oracle (CPU restatement of the reference kernels in the reference's unfused
-    launch order) timed on this host's cores on the same workload."""
-    from oracle import oracle as O
-    O.build()
-    cores = O.get_max_threads()
+def _oracle_steps(O, law, grid, direction, dt, budget_s, max_steps, warm_rhs=True):
     dg = O.OracleDGModel(law, grid, nf_first=0, direction=direction[0],
                          diffusion_direction=direction[1])
     Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
     dQ = np.zeros_like(Q)
-    O.lsrk54_step(dg, Q, dQ, 0.0, dt)           # warm-up (page faults, thread pool)
+    if warm_rhs:                                 # page faults + thread pool: one RHS evaluation
+        dg(np.zeros_like(Q), Q.copy(), 0.0, 1.0, 0.0)
     n, t0 = 0, time.time()
     while True:
         O.lsrk54_step(dg, Q, dQ, n * dt, dt)
         n += 1
         el = time.time() - t0
-        if el > budget_s or n >= 50:
+        if el > budget_s or n >= max_steps:
             break
-    dofs = grid.nreal * grid.Np * law.ns * 5 * n
-    return {"value": dofs / el, "unit": "DOF-updates/s", "cores": cores, "kind": "port",
-            "sample": "%d LSRK54 step(s) of the same workload (%d elements) in %.1f s, "
-                      "OpenMP over elements" % (n, grid.nreal, el)}
+    return grid.nreal * grid.Np * law.ns * 5 * n / el, n, el
+
+
+def cpu_baseline(cm, law, grid, direction, dt, budget_s, args):
+    """The oracle (CPU restatement of the reference kernels in the reference's unfused launch
+    order: horizontal then vertical volume kernel, per-direction interface launches, separate
+    auxiliary pass, separate update!) timed on this host's cores: all of them on the workload
+    itself, and one core on a smaller sphere of the same workload (a full-size step would take
+    minutes on one core)."""
+    from oracle import oracle as O
+    O.build()
+    cores = O.get_max_threads()
+    v, n, el = _oracle_steps(O, law, grid, direction, dt, budget_s, 50)
+    out = {"value": v, "unit": "DOF-updates/s", "cores": cores, "kind": "port",
+           "sample": "%d LSRK54 step(s) of the same workload (%d elements) in %.1f s, "
+                     "OpenMP over elements, after one untimed RHS evaluation" % (n, grid.nreal, el)}
+    if args.workload == "heldsuarez":
+        law1, grid1, dir1, dt1, _ = build_workload(cm, "heldsuarez", 0, 1, 0, args, nhorz=4)
+        O.set_num_threads(1)
+        try:
+            v1, n1, el1 = _oracle_steps(O, law1, grid1, dir1, dt1, budget_s, 50)
+        finally:
+            O.set_num_threads(cores)
+        out["one_core"] = {"value": v1, "unit": "DOF-updates/s", "cores": 1,
+                           "sample": "%d LSRK54 step(s) of the same workload on a 6x4x4x%d sphere "
+                                     "(%d elements) in %.1f s, one thread" % (
+                                         n1, args.nvert, grid1.nreal, el1)}
+    return out
+
+
+def parity_check(cm, args, dev):
+    """GPU vs oracle on the same workload at a size the oracle finishes in seconds, outside the
+    timed region: one RHS evaluation (tendency, per prognostic state, L-inf relative) and two
+    LSRK54 steps (state).  A failure aborts the benchmark: a fast wrong answer is no answer."""
+    import torch
+    from oracle import oracle as O
+    O.build()
+    if args.workload != "heldsuarez":
+        return None
+    law, grid, direction, dt, _ = build_workload(cm, args.workload, 0, 1, 4, args, nhorz=3, nvert=2)
+    dg = cm.dgmodel.DGModel(law, grid, direction=direction[0], diffusion_direction=direction[1],
+                            device=dev)
+    odg = O.OracleDGModel(law, grid, nf_first=0, direction=direction[0],
+                          diffusion_direction=direction[1])
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    rng = np.random.default_rng(20250117)
+    Q0[:, 1:4] += 0.5 * rng.standard_normal(Q0[:, 1:4].shape)
+    Q0[:, 4] *= 1 + 1e-3 * rng.standard_normal(Q0[:, 4].shape)
+    To = np.zeros_like(Q0)
+    odg(To, Q0.copy(), 0.0, 1.0, 0.0)
+    Q = torch.from_numpy(Q0.copy()).to(dev)
+    Tg = dg.create_state()
+    torch.cuda.synchronize()
+    dg(Tg, Q, 0.0, 1.0, 0.0)
+    Tg = Tg.cpu().numpy()
+    nr = grid.nreal
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    tend = [rel(Tg[:nr, s], To[:nr, s]) for s in range(law.ns)]
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+    solver.dostep(Q, nsteps=2)
+    dg.synchronize()
+    Qo, dQo = Q0.copy(), np.zeros_like(Q0)
+    for s in range(2):
+        O.lsrk54_step(odg, Qo, dQo, s * dt, dt)
+    Qg = Q.cpu().numpy()
+    state = [rel(Qg[:nr, s], Qo[:nr, s]) for s in range(law.ns)]
+    dg.close()
+    tol = 1e-12
+    out = {"against": "oracle (CPU restatement), same inputs, 6x3x3x2 sphere",
+           "tendency_rel_linf": max(tend), "state_rel_linf_2_steps": max(state), "tolerance": tol,
+           "ok": bool(max(tend) < tol and max(state) < tol)}
+    if not out["ok"]:
+        raise SystemExit("bench.py: GPU != oracle: %s" % json.dumps(out))
+    return out
+
+
+def timed_run(cm, dg, law, grid, dt, steps, warmup, sync_all, distributed, dev):
+    """W warm-up steps, then K timed steps bracketed by barrier + synchronize."""
+    import torch
+    import torch.distributed as dist
+    Q = dg.init_ode_state(0.0)
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+    solver.dostep(Q, nsteps=warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    solver.dostep(Q, nsteps=steps)
+    dg.synchronize()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if distributed:
+        dist.barrier()
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    return Q, solver, el
 
 
 def main():
@@ -176,6 +275,13 @@ def main():
     ap.add_argument("--bomex-ne", type=int, default=16,
                     help="bomex: ne x ne x 2 ne elements per rank (32: the 65 536 elements of configs[3])")
     ap.add_argument("--nhorz", type=int, default=0, help="heldsuarez: elements per cube edge")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "weak-small"],
+                    help="heldsuarez: weak = 43 200 elements per GPU (n_horz 30/42/60/85 at "
+                         "1/2/4/8 GPUs), strong = the 6x30x30x8 sphere split over the GPUs, "
+                         "weak-small = ~5 400 elements per GPU (n_horz 11/15/21/30)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run GPU vs oracle check")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary n_horz = 11 measurement of the one-GPU default run")
     ap.add_argument("--nvert", type=int, default=8, help="heldsuarez: vertical elements")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline")
     ap.add_argument("--filter", action="store_true",
@@ -210,6 +316,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device(dev))
 
+    parity = None
+    if rank == 0 and world == 1 and not args.no_parity and not args.no_cpu:
+        parity = parity_check(cm, args, dev)
+        log("[parity] %s" % json.dumps(parity))
     t0 = time.time()
     law, grid, direction, dt, desc = build_workload(cm, args.workload, rank, world, args.ne, args)
     log("[rank %d] mesh+grid: %d real + %d ghost elements in %.1f s" % (
@@ -224,8 +334,6 @@ def main():
         dist.broadcast(uid, 0)
         dg.comm_init_rccl(uid.cpu().numpy().tobytes(), rank, world)
         dg.comm_selftest()
-    Q = dg.init_ode_state(0.0)
-    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
     step_filter = None
     if args.filter:
         assert args.workload in ("heldsuarez", "bomex")
@@ -246,20 +354,10 @@ def main():
         if distributed:
             dist.barrier()
 
-    solver.dostep(Q, nsteps=args.warmup)
-    sync_all()
     # ---- timed region: K steps, nothing but the library's own launches in flight ----------
-    t0 = time.perf_counter()
-    solver.t = args.warmup * dt
-    solver.dostep(Q, nsteps=args.steps)
-    dg.synchronize()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    Q, solver, el = timed_run(cm, dg, law, grid, dt, args.steps, args.warmup, sync_all,
+                              distributed, dev)
     if distributed:
-        dist.barrier()
-        tt = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
         nn = torch.tensor([grid.nreal], device=dev, dtype=torch.int64)
         dist.all_reduce(nn, op=dist.ReduceOp.SUM)
         total_elems = int(nn.item())
@@ -302,7 +400,8 @@ def main():
         # profiles/r01_pmc_calibration_n30.json confirms for this library's 8-byte-per-lane
         # loads); only quoted for the configuration it was measured on
         traffic, traffic_src = None, None
-        pmc_files = {("heldsuarez", 5808): "r01_heldsuarez_n11_pmc_hbm_per_launch.json",
+        pmc_files = {("heldsuarez", 43200): "r02_heldsuarez_n30_pmc_hbm_per_launch.json",
+                     ("heldsuarez", 5808): "r01_heldsuarez_n11_pmc_hbm_per_launch.json",
                      ("risingbubble", 8000): "r01_risingbubble_8000_pmc_hbm_per_launch.json",
                      ("bomex", 8192): "r01_bomex_n6_8192_pmc_hbm_per_launch.json"}
         pmc_name = pmc_files.get((args.workload, grid.nreal))
@@ -317,14 +416,17 @@ def main():
             "metric": "DG RHS DOF-updates/sec", "value": dofs / el, "unit": "DOF-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if (args.workload == "heldsuarez" and args.scaling == "strong") else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": desc,
             "node_updates_per_s": dofs / el / law.ns,
             "state_finite": finite,
             "kernels_ms": {k: {"avg_ms": v[0], "launches": v[1]} for k, v in kern.items()},
             "roofline": {"bound": "hbm", "kernel": "k_%s" % dom.lower(), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic,
+                         "traffic_source": ("committed rocprofv3 --pmc profile of this command, not "
+                                            "measured in this run: " + traffic_src) if traffic_src else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "algorithmic_bytes_per_node": algorithmic_bytes_per_node(law, dom, grid.N[0] + 1),
                          "avg_launch_ms": avg_ms,
@@ -346,9 +448,29 @@ def main():
             out["filter_kernel"] = {"avg_launch_ms": kern["FILTER"][0],
                                     "algorithmic_bytes_per_node": 8 * (2 * law.ns + 2),
                                     "achieved_GBs": fb / (kern["FILTER"][0] * 1e-3) / 1e9}
+        if parity is not None:
+            out["parity"] = parity
+        if (world == 1 and args.workload == "heldsuarez" and not args.nhorz and not args.filter
+                and args.scaling == "weak" and not args.no_secondary):
+            # the round-1 headline size (SURVEY section 8(d)'s weak-scaling base of ~5 400 elements
+            # per GPU), so that numbers of that family stay comparable
+            law2, grid2, dir2, dt2, desc2 = build_workload(cm, "heldsuarez", 0, 1, 0, args, nhorz=11)
+            dg2 = cm.dgmodel.DGModel(law2, grid2, direction=dir2[0], diffusion_direction=dir2[1],
+                                     device=dev)
+
+            def sync2():
+                dg2.synchronize()
+                torch.cuda.synchronize()
+            _, _, el2 = timed_run(cm, dg2, law2, grid2, dt2, args.steps, args.warmup, sync2, False, dev)
+            dg2.close()
+            out["secondary"] = {"workload": desc2["workload"], "elements": grid2.nreal,
+                                "value": grid2.nreal * grid2.Np * law2.ns * 5 * args.steps / el2,
+                                "ms_per_step": 1e3 * el2 / args.steps}
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(law, grid, direction, dt, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(cm, law, grid, direction, dt, args.cpu_budget, args)
         print(json.dumps(out), flush=True)
+        if not finite:
+            raise SystemExit("bench.py: the state is not finite after the timed steps")
     if step_filter is not None:
         dg.set_filters()
         step_filter.close()

@@ -141,7 +141,6 @@ int EngineBase::init(const cmdg_desc *d)
         nabrsend.assign(d->nabrtovmapsend, d->nabrtovmapsend + 2 * d->nnabr);
         nabrrecv.assign(d->nabrtovmaprecv, d->nabrtovmaprecv + 2 * d->nnabr);
     }
-    int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     HIPCHK(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&s_comm, hipStreamNonBlocking));
@@ -250,7 +249,6 @@ int EngineBase::halo_begin(int s, double *array, int nvar)
     HaloSlot &h = slot[s];
     if (h.active) return fail(CMDG_ERR_INVALID, "The current ghost exchange must end before another begins.");
     if (nvar > slot_nvar_max) return fail(CMDG_ERR_INVALID, "halo: nstate too large for the buffers");
-    h.active = true;
     h.nvar = nvar;
     h.array = array;
     // the data to send is produced on the compute stream
@@ -287,7 +285,13 @@ int EngineBase::halo_begin(int s, double *array, int nvar)
         if (int rc = rccl::GroupEnd())
             return fail(CMDG_ERR_COMM, std::string("ncclGroupEnd: ") + rccl::GetErrorString(rc));
     }
+    h.active = true;  // only now: a failure above leaves the slot free for the next call
     return CMDG_OK;
+}
+
+void EngineBase::abort_exchanges()
+{
+    for (auto &h : slot) h.active = false;
 }
 
 int EngineBase::halo_end(int s, double *array, int nvar)
@@ -415,7 +419,10 @@ int EngineBase::rhs_async(const RhsCtx &c)
     if (transport == TRANSPORT_LOCAL && communicate())
         return fail(CMDG_ERR_INVALID, "handles connected locally must be driven by the cmdg_group_* calls");
     for (int s = 0; s < NSEG; ++s)
-        if (int r = rhs_segment(s, c)) return r;
+        if (int r = rhs_segment(s, c)) {
+            abort_exchanges();
+            return r;
+        }
     return CMDG_OK;
 }
 
@@ -442,7 +449,10 @@ int group_rhs(std::vector<EngineBase *> &g, std::vector<RhsCtx> &c)
 {
     for (int s = 0; s < EngineBase::NSEG; ++s)
         for (size_t i = 0; i < g.size(); ++i)
-            if (int r = g[i]->rhs_segment(s, c[i])) return r;
+            if (int r = g[i]->rhs_segment(s, c[i])) {
+                for (auto *e : g) e->abort_exchanges();
+                return r;
+            }
     return CMDG_OK;
 }
 
@@ -611,8 +621,8 @@ int EngineBase::set_hooks(const cmdg_rhs_hooks *hk)
             return fail(CMDG_ERR_INVALID, "hooks: copy column out of range");
     for (int i = 0; i < hk->nsurf; ++i)
         if (hk->surf_src_col[i] < 0 || hk->surf_src_col[i] >= naux || hk->surf_dst_col[i] < 0 ||
-            hk->surf_dst_col[i] >= naux)
-            return fail(CMDG_ERR_INVALID, "hooks: surface column out of range");
+            hk->surf_dst_col[i] >= naux || hk->surf_src_col[i] == hk->surf_dst_col[i])
+            return fail(CMDG_ERR_INVALID, "hooks: surface column out of range (or source == destination)");
     for (int i = 0; i < hk->npre; ++i)
         if (!hk->pre_filter[i]) return fail(CMDG_ERR_INVALID, "hooks: NULL filter");
     if (hk->has_flow_deviation) {
@@ -952,7 +962,16 @@ int cmdg_create(const cmdg_desc *d, cmdg_handle *out)
 int cmdg_destroy(cmdg_handle h)
 {
     if (!h) return CMDG_ERR_INVALID;
-    delete h->eng;
+    {
+        DevGuard guard_(h->eng);
+        // members of a local group keep pointers to each other: detach the survivors
+        for (EngineBase *peer : h->eng->group)
+            if (peer && peer != h->eng) {
+                peer->group.clear();
+                peer->transport = TRANSPORT_NONE;
+            }
+        delete h->eng;
+    }
     delete h;
     return CMDG_OK;
 }
@@ -966,6 +985,7 @@ const char *cmdg_last_error(cmdg_handle h)
 int cmdg_rhs_async(cmdg_handle h, double *tendency, double *Q, double t, double alpha, double beta)
 {
     if (!h || !tendency || !Q) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     RhsCtx c;
     c.tendency = tendency;
     c.Qin = Q;
@@ -979,6 +999,7 @@ int cmdg_rhs(cmdg_handle h, double *tendency, double *Q, double t, double alpha,
 {
     int r = cmdg_rhs_async(h, tendency, Q, t, alpha, beta);
     if (r) return r;
+    DevGuard guard_(h->eng);
     return set_err(h, h->eng->synchronize());
 }
 
@@ -986,6 +1007,7 @@ int cmdg_lsrk_step(cmdg_handle h, double *Q, double *dQ, double t, double dt, in
                    const double *rka, const double *rkb, const double *rkc)
 {
     if (!h || !Q || !dQ || !rka || !rkb || !rkc) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     return set_err(h, h->eng->lsrk_step(Q, dQ, t, dt, nstages, rka, rkb, rkc));
 }
 
@@ -993,6 +1015,7 @@ int cmdg_lsrk_run(cmdg_handle h, double *Q, double *dQ, double t, double dt, int
                   int32_t nstages, const double *rka, const double *rkb, const double *rkc)
 {
     if (!h || !Q || !dQ || !rka || !rkb || !rkc) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     for (int64_t i = 0; i < nsteps; ++i) {
         int r = h->eng->lsrk_step(Q, dQ, t + i * dt, dt, nstages, rka, rkb, rkc);
         if (r) return set_err(h, r);
@@ -1003,17 +1026,20 @@ int cmdg_lsrk_run(cmdg_handle h, double *Q, double *dQ, double t, double dt, int
 int cmdg_synchronize(cmdg_handle h)
 {
     if (!h) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     return set_err(h, h->eng->synchronize());
 }
 
 int cmdg_halo_begin(cmdg_handle h, double *array, int32_t nstate)
 {
     if (!h || !array) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     return set_err(h, h->eng->halo_begin(SLOT_Q, array, nstate));
 }
 int cmdg_halo_end(cmdg_handle h, double *array, int32_t nstate)
 {
     if (!h || !array) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     return set_err(h, h->eng->halo_end(SLOT_Q, array, nstate));
 }
 
@@ -1034,6 +1060,7 @@ int cmdg_comm_unique_id(void *out128)
 int cmdg_comm_init_rccl(cmdg_handle h, const void *unique_id128, int32_t rank, int32_t nranks)
 {
     if (!h || !unique_id128 || rank < 0 || rank >= nranks) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     EngineBase *e = h->eng;
     if (!rccl::load(e->err)) return set_err(h, CMDG_ERR_COMM);
     rccl::uid_t id;
@@ -1050,6 +1077,7 @@ int cmdg_comm_init_rccl(cmdg_handle h, const void *unique_id128, int32_t rank, i
 int cmdg_comm_selftest(cmdg_handle h, int64_t count)
 {
     if (!h || count < 1) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     EngineBase *e = h->eng;
     if (e->transport != TRANSPORT_RCCL || !e->nccl_comm)
         return set_err(h, e->fail(CMDG_ERR_COMM, "selftest: RCCL transport not initialised"));
@@ -1086,6 +1114,8 @@ int cmdg_comm_connect_local(cmdg_handle *handles, int32_t n)
     for (int i = 0; i < n; ++i) {
         if (!handles[i]) return CMDG_ERR_INVALID;
         g.push_back(handles[i]->eng);
+        if (g[i]->dev != g[0]->dev)
+            return set_err(handles[i], g[i]->fail(CMDG_ERR_INVALID, "local transport: the handles of a group live on one device"));
     }
     for (int i = 0; i < n; ++i) {
         g[i]->group = g;
@@ -1102,6 +1132,9 @@ int cmdg_group_rhs(cmdg_handle *handles, int32_t n, double **tendency, double **
                    double alpha, double beta)
 {
     if (!handles || n < 1 || !tendency || !Q) return CMDG_ERR_INVALID;
+    for (int i = 0; i < n; ++i)
+        if (!handles[i] || !tendency[i] || !Q[i]) return CMDG_ERR_INVALID;
+    DevGuard guard_(handles[0]->eng);
     std::vector<EngineBase *> g;
     std::vector<RhsCtx> c(n);
     for (int i = 0; i < n; ++i) {
@@ -1122,6 +1155,9 @@ int cmdg_group_halo(cmdg_handle *handles, int32_t n, double **arrays, int32_t ns
 {
     if (!handles || n < 1 || !arrays) return CMDG_ERR_INVALID;
     for (int i = 0; i < n; ++i)
+        if (!handles[i] || !arrays[i]) return CMDG_ERR_INVALID;
+    DevGuard guard_(handles[0]->eng);
+    for (int i = 0; i < n; ++i)
         if (int r = handles[i]->eng->halo_begin(SLOT_Q, arrays[i], nstate)) return set_err(handles[i], r);
     for (int i = 0; i < n; ++i)
         if (int r = handles[i]->eng->halo_end(SLOT_Q, arrays[i], nstate)) return set_err(handles[i], r);
@@ -1135,6 +1171,9 @@ int cmdg_group_lsrk_run(cmdg_handle *handles, int32_t n, double **Q, double **dQ
                         const double *rkb, const double *rkc)
 {
     if (!handles || n < 1 || !Q || !dQ || !rka || !rkb || !rkc) return CMDG_ERR_INVALID;
+    for (int i = 0; i < n; ++i)
+        if (!handles[i] || !Q[i] || !dQ[i]) return CMDG_ERR_INVALID;
+    DevGuard guard_(handles[0]->eng);
     std::vector<EngineBase *> g;
     for (int i = 0; i < n; ++i) g.push_back(handles[i]->eng);
     for (int64_t s = 0; s < nsteps; ++s) {
@@ -1151,12 +1190,14 @@ int cmdg_norm2_local(cmdg_handle h, const double *A, int32_t nstate, int32_t wei
                      double *out_host)
 {
     if (!h || !A || !out_host) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     return set_err(h, h->eng->wsum2(A, nullptr, nstate, weighted, out_host));
 }
 int cmdg_distance2_local(cmdg_handle h, const double *A, const double *B, int32_t nstate,
                          double *out_host)
 {
     if (!h || !A || !B || !out_host) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     return set_err(h, h->eng->wsum2(A, B, nstate, 1, out_host));
 }
 
@@ -1164,12 +1205,14 @@ int cmdg_courant(cmdg_handle h, int32_t kind, const double *Q, double dt, double
                  int32_t direction, double *out_host)
 {
     if (!h || !Q || !out_host) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     return set_err(h, h->eng->courant(1, kind, Q, dt, simtime, direction, out_host));
 }
 
 int cmdg_min_node_distance(cmdg_handle h, int32_t direction, double *out_host)
 {
     if (!h || !out_host) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     return set_err(h, h->eng->courant(0, 0, nullptr, 0.0, 0.0, direction, out_host));
 }
 
@@ -1178,6 +1221,7 @@ int cmdg_indefinite_stack_integral(cmdg_handle h, const double *Q, int32_t nstat
                                    const cmdg_stack_integral_desc *d)
 {
     if (!h || !aux || !d || naux < 1) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     return set_err(h, h->eng->stack_integral(false, Q, nstate, aux, naux, nvertelem, Imat, d));
 }
 
@@ -1185,12 +1229,14 @@ int cmdg_reverse_indefinite_stack_integral(cmdg_handle h, double *aux, int32_t n
                                            int32_t nvertelem, const cmdg_stack_integral_desc *d)
 {
     if (!h || !aux || !d || naux < 1) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     return set_err(h, h->eng->stack_integral(true, nullptr, 0, aux, naux, nvertelem, nullptr, d));
 }
 
 int cmdg_filter_create(cmdg_handle h, const cmdg_filter_desc *d, cmdg_filter *out)
 {
     if (!h || !d || !out) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     FilterObj *f = nullptr;
     int r = h->eng->filter_create(d, &f);
     *out = reinterpret_cast<cmdg_filter>(f);
@@ -1200,12 +1246,20 @@ int cmdg_filter_create(cmdg_handle h, const cmdg_filter_desc *d, cmdg_filter *ou
 int cmdg_filter_destroy(cmdg_handle h, cmdg_filter f)
 {
     if (!h || !f) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     EngineBase *e = h->eng;
     FilterObj *o = reinterpret_cast<FilterObj *>(f);
     e->synchronize();
     if (e->gradient_filter == o) e->gradient_filter = nullptr;
     if (e->tendency_filter == o) e->tendency_filter = nullptr;
     if (e->step_filter == o) e->step_filter = nullptr;
+    // a recorded update_auxiliary_state! composition may name this filter: drop it from there
+    {
+        int k = 0;
+        for (int i = 0; i < e->hooks.npre; ++i)
+            if (e->hooks.pre_filter[i] != f) e->hooks.pre_filter[k++] = e->hooks.pre_filter[i];
+        e->hooks.npre = k;
+    }
     if (o->d_Fh) hipFree(o->d_Fh);
     if (o->d_Fv) hipFree(o->d_Fv);
     delete o;
@@ -1215,6 +1269,7 @@ int cmdg_filter_destroy(cmdg_handle h, cmdg_filter f)
 int cmdg_filter_apply(cmdg_handle h, cmdg_filter f, double *Q, int32_t nstate)
 {
     if (!h || !f || !Q || nstate < 1) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     return set_err(h, h->eng->filter_apply(reinterpret_cast<FilterObj *>(f), Q, nstate));
 }
 
@@ -1222,6 +1277,7 @@ int cmdg_set_filters(cmdg_handle h, cmdg_filter gradient_filter, cmdg_filter ten
                      cmdg_filter step_filter)
 {
     if (!h) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     EngineBase *e = h->eng;
     auto *gfl = reinterpret_cast<FilterObj *>(gradient_filter);
     auto *tfl = reinterpret_cast<FilterObj *>(tendency_filter);
@@ -1237,18 +1293,21 @@ int cmdg_set_filters(cmdg_handle h, cmdg_filter gradient_filter, cmdg_filter ten
 int cmdg_set_rhs_hooks(cmdg_handle h, const cmdg_rhs_hooks *hooks)
 {
     if (!h) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     return set_err(h, h->eng->set_hooks(hooks));
 }
 
 int cmdg_profile_enable(cmdg_handle h, int32_t on)
 {
     if (!h) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     h->eng->profiling = on != 0;
     return CMDG_OK;
 }
 int cmdg_profile_get(cmdg_handle h, int32_t kernel, double *total_ms, int64_t *launches)
 {
     if (!h || kernel < 0 || kernel >= CMDG_K_COUNT) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     h->eng->synchronize();
     h->eng->prof_collect();
     if (total_ms) *total_ms = h->eng->prof_ms[kernel];
@@ -1258,6 +1317,7 @@ int cmdg_profile_get(cmdg_handle h, int32_t kernel, double *total_ms, int64_t *l
 int cmdg_profile_reset(cmdg_handle h)
 {
     if (!h) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     h->eng->synchronize();
     h->eng->prof_collect();
     for (int i = 0; i < CMDG_K_COUNT; ++i) {

@@ -69,6 +69,7 @@ struct EngineBase {
     double *derived = nullptr;  // (Np, NDER, nelem), library-owned
     bool own_gf = false, own_hg = false, own_hd = false;
     // ---- runtime -----------------------------------------------------------------------
+    int dev = 0;  // the device this engine was created on (every ABI entry binds to it)
     hipStream_t s_comp = nullptr, s_comm = nullptr;
     hipEvent_t ev_comp = nullptr;
     HaloSlot slot[NSLOT];
@@ -117,6 +118,7 @@ struct EngineBase {
                   const double *rkb, const double *rkc);
     int halo_begin(int s, double *array, int nvar);
     int halo_end(int s, double *array, int nvar);
+    void abort_exchanges();  // after a failed call: no exchange is left "begun"
     int ensure_work();
     int synchronize();
     int wsum2(const double *A, const double *B, int nvar, int weighted, double *out);
@@ -151,6 +153,27 @@ struct cmdg_context {
     cmdg::EngineBase *eng = nullptr;
     std::string err;
 };
+
+namespace cmdg {
+// Every ABI entry runs with the engine's device current: lazily allocated work buffers and the
+// kernels of a handle land on the GPU the handle was created on, whatever device the calling
+// thread switched to in between; the caller's current device is restored on return.
+struct DevGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DevGuard(const EngineBase *e)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != e->dev)
+            changed = hipSetDevice(e->dev) == hipSuccess;
+    }
+    ~DevGuard()
+    {
+        if (changed) (void)hipSetDevice(prev);
+    }
+    DevGuard(const DevGuard &) = delete;
+    DevGuard &operator=(const DevGuard &) = delete;
+};
+}  // namespace cmdg
 
 namespace cmdg {
 

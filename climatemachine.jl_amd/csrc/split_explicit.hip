@@ -150,6 +150,7 @@ extern "C" {
 int cmdg_ocean_initialize_states(cmdg_handle slow, cmdg_handle fast, const cmdg_ocean_coupling_desc *d)
 {
     if (int r = check(slow, fast, d)) return set_err2(slow, r);
+    DevGuard guard_(slow->eng);
     initialize_states(slow->eng, d);
     return set_err2(slow, launch_status(slow->eng));
 }
@@ -158,6 +159,7 @@ int cmdg_ocean_tendency_from_slow_to_fast(cmdg_handle slow, cmdg_handle fast,
                                           const cmdg_ocean_coupling_desc *d, const double *dQ_slow)
 {
     if (int r = check(slow, fast, d)) return set_err2(slow, r);
+    DevGuard guard_(slow->eng);
     if (!dQ_slow) return CMDG_ERR_INVALID;
     if (int r = slow_to_fast(slow->eng, fast->eng, d, dQ_slow)) return set_err2(slow, r);
     return set_err2(slow, launch_status(slow->eng));
@@ -168,6 +170,7 @@ int cmdg_ocean_reconcile_from_fast_to_slow(cmdg_handle slow, cmdg_handle fast,
                                            const double *Q_fast)
 {
     if (int r = check(slow, fast, d)) return set_err2(slow, r);
+    DevGuard guard_(slow->eng);
     if (!Q_slow || !Q_fast) return CMDG_ERR_INVALID;
     if (int r = fast_to_slow(slow->eng, fast->eng, d, Q_slow, Q_fast)) return set_err2(slow, r);
     return set_err2(slow, launch_status(slow->eng));
@@ -176,6 +179,7 @@ int cmdg_ocean_reconcile_from_fast_to_slow(cmdg_handle slow, cmdg_handle fast,
 int cmdg_lsrk_update(cmdg_handle h, double *dQ, double *Q, double rka_next, double rkb_dt)
 {
     if (!h || !dQ || !Q) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     lsrk_update(h->eng, dQ, Q, rka_next, rkb_dt);
     return set_err2(h, launch_status(h->eng));
 }
@@ -184,9 +188,10 @@ int cmdg_ls3n_step(cmdg_handle h, double *Q, double *dQ, double *dR, double t, d
                    int32_t nstages, const double *rka, const double *rkb, const double *rkc)
 {
     if (!h || !Q || !dQ || !dR || !rka || !rkb || !rkc || nstages < 1) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     EngineBase *e = h->eng;
     const int64_t n = (int64_t)e->Np * e->ns * e->nreal;
-    hipLaunchKernelGGL(k_fill, dim3(nblocks(n)), dim3(256), 0, e->s_comp, dR, -0.0, n);
+    hipLaunchKernelGGL(k_fill, dim3(nblocks(n)), dim3(256), 0, e->s_comp, dR, 0.0, n);  // `rv_dR .= -0`: integer -0, i.e. +0.0
     for (int s = 0; s < nstages; ++s) {
         RhsCtx c;
         c.tendency = dQ;
@@ -206,6 +211,7 @@ int cmdg_ssprk_step(cmdg_handle h, double *Q, double *Rstage, double *Qstage, do
                     int32_t nstages, const double *rka, const double *rkb, const double *rkc)
 {
     if (!h || !Q || !Rstage || !Qstage || !rka || !rkb || !rkc || nstages < 1) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
     EngineBase *e = h->eng;
     const int64_t n = (int64_t)e->Np * e->ns * e->nreal;
     if (hipMemcpyAsync(Qstage, Q, sizeof(double) * n, hipMemcpyDeviceToDevice, e->s_comp) != hipSuccess)
@@ -237,6 +243,8 @@ static int group_split_explicit_step(int n, cmdg_handle *slow, cmdg_handle *fast
                                      const double *rka, const double *rkb, const double *rkc)
 {
     std::vector<EngineBase *> S(n), F(n);
+    if (!slow[0]) return CMDG_ERR_INVALID;
+    DevGuard guard_(slow[0]->eng);
     for (int i = 0; i < n; ++i) {
         if (int r = check(slow[i], fast[i], d)) return set_err2(slow[i], r);
         if (!Q3[i] || !dQ3[i] || !dQ2fast[i] || !Q2[i] || !dQ2[i]) return CMDG_ERR_INVALID;

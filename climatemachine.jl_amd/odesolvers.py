@@ -24,6 +24,13 @@ def _f(num, den):
     return float(Fraction(num, den))
 
 
+def _advance(solver, nsteps, dt):
+    # updatetime!: t += dt once per step (the running sum, not t0 + n * dt)
+    for _ in range(int(nsteps)):
+        solver.t += dt
+    solver.steps += int(nsteps)
+
+
 class LowStorageRungeKutta2N:
     def __init__(self, dg, RKA, RKB, RKC, Q, dt=0.0, t0=0.0):
         self.dg = dg
@@ -33,8 +40,11 @@ class LowStorageRungeKutta2N:
         self.dQ = dg.create_state(Q.shape[1])          # zero initialised (:52-53)
 
     def dostep(self, Q, nsteps=1, dt=None):
+        """``nsteps`` steps of size ``dt`` from ``self.t``; the solver's time and step count
+        advance as ``general_dostep!`` / ``updatetime!`` do (ODESolvers.jl:56-73, 96-98)."""
         dt = self.dt if dt is None else dt
         self.dg.lsrk_run(Q, self.dQ, self.t, dt, nsteps, self.RKA, self.RKB, self.RKC)
+        _advance(self, nsteps, dt)
 
 
 def LSRK54CarpenterKennedy(dg, Q, dt=0.0, t0=0.0):
@@ -107,6 +117,7 @@ class StrongStabilityPreservingRungeKutta:
                 self.dg.handle, Q.data_ptr(), self.Rstage.data_ptr(), self.Qstage.data_ptr(),
                 float(self.t + i * dt), float(dt), len(self.RKB), p(self.RKA), p(self.RKB),
                 p(self.RKC)), self.dg.handle)
+        _advance(self, nsteps, dt)
 
 
 def _ssp(name):
@@ -156,6 +167,7 @@ class LowStorageRungeKutta3N:
                 self.dg.handle, Q.data_ptr(), self.dQ.data_ptr(), self.dR.data_ptr(),
                 float(self.t + i * dt), float(dt), len(self.RKC), p(self.RKA), p(self.RKB),
                 p(self.RKC)), self.dg.handle)
+        _advance(self, nsteps, dt)
 
 
 def _ls3n(name):
@@ -173,23 +185,17 @@ def solve(Q, solver, timeend=None, numberofsteps=0, adjustfinalstep=True):
     whole steps are batched into one library call, the last (shortened) step is
     issued separately like ``general_dostep!`` does."""
     assert timeend is not None or numberofsteps > 0
-    t, dt = solver.t, solver.dt
+    dt = solver.dt
     assert dt > 0
     step = 0
-    while (timeend is None or t < timeend):
-        if timeend is not None and adjustfinalstep and t + dt > timeend:
-            solver.t = t
-            solver.dostep(Q, 1, dt=timeend - t)
-            t = timeend
-            step += 1
+    while (timeend is None or solver.t < timeend):
+        if timeend is not None and adjustfinalstep and solver.t + dt > timeend:
+            solver.dostep(Q, 1, dt=timeend - solver.t)
+            solver.t = timeend
         else:
-            solver.t = t
             solver.dostep(Q, 1)
-            t = t + dt
-            step += 1
+        step += 1
         if step == numberofsteps:
             break
-    solver.t = t
-    solver.steps = step
     solver.dg.synchronize()
-    return t
+    return solver.t

@@ -66,13 +66,9 @@ def test_sphere_diffusion_on_the_gpu(cm, torch, hyper, level):
     solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
     # whole steps in one library call, then the shortened last step (solve! semantics)
     n = int(np.floor(1.0 / dt + 1e-12))
-    t = 0.0
-    for _ in range(n):
-        t += dt
-    solver.dostep(Q, nsteps=n)
-    solver.t = t
-    if t < 1.0:
-        solver.dostep(Q, nsteps=1, dt=1.0 - t)
+    solver.dostep(Q, nsteps=n)              # advances solver.t as updatetime! does
+    if solver.t < 1.0:
+        solver.dostep(Q, nsteps=1, dt=1.0 - solver.t)
     dg.synchronize()
     Qe = dg.init_ode_state(1.0)
     err = dg.euclidean_distance(Q, Qe)
