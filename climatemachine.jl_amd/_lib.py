@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("CMDG_LIB", os.path.join(_HERE, "libcmdg.so"))   # CMD
 CMDG_K = dict(GRADIENTS=0, DIVGRAD=1, GRADLAP=2, TENDENCY=3, PACK=4, UNPACK=5, UPDATE_AUX=6,
               FILTER=7, STACK_INTEGRAL=8)
 STACK_MAXOUT = 8
+OPT_KEEP_GRADFLUX = 1
 
 
 class CmdgStackIntegralDesc(C.Structure):
@@ -91,6 +92,7 @@ SYMBOLS = [
     ("cmdg_lsrk_step", C.c_int, [_vp, _vp, _vp, _d, _d, _i32, _vp, _vp, _vp]),
     ("cmdg_lsrk_run", C.c_int, [_vp, _vp, _vp, _d, _d, _i64, _i32, _vp, _vp, _vp]),
     ("cmdg_synchronize", C.c_int, [_vp]),
+    ("cmdg_set_option", C.c_int, [_vp, _i32, _i32]),
     ("cmdg_halo_begin", C.c_int, [_vp, _vp, _i32]),
     ("cmdg_halo_end", C.c_int, [_vp, _vp, _i32]),
     ("cmdg_comm_unique_id", C.c_int, [_vp]),

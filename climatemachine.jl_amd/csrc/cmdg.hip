@@ -81,6 +81,8 @@ EngineBase::~EngineBase()
     if (W[0]) hipFree(W[0]);
     if (W[1]) hipFree(W[1]);
     if (d_D) hipFree(d_D);
+    if (d_faceP) hipFree(d_faceP);
+    if (d_faceG) hipFree(d_faceG);
     if (derived) hipFree(derived);
     if (d_partial) hipFree(d_partial);
     if (d_elemred) hipFree(d_elemred);
@@ -153,6 +155,34 @@ int EngineBase::init(const cmdg_desc *d)
         HIPCHK(hipMalloc(&d_Dv, sizeof(double) * NQV * NQV));
         HIPCHK(hipMemcpy(d_Dv, d->Dv, sizeof(double) * NQV * NQV, hipMemcpyHostToDevice));
         g.Dv = d_Dv;
+    }
+    {
+        // digest of the face tables: one pass over the reference's arrays, checked as it goes
+        const int NFT = 4 * NQ * NQV + 2 * NQ * NQ;
+        const int64_t nt = std::max<int64_t>(nreal, 1) * NFT;
+        int *d_bad = nullptr, bad = 0;
+        HIPCHK(hipMalloc(&d_faceP, sizeof(int32_t) * nt));
+        HIPCHK(hipMalloc(&d_faceG, sizeof(double) * 4 * nt));
+        HIPCHK(hipMalloc(&d_bad, sizeof(int)));
+        HIPCHK(hipMemset(d_bad, 0, sizeof(int)));
+        if (nreal > 0)
+            hipLaunchKernelGGL(k_face_digest, dim3((unsigned)((nreal * NFT + 255) / 256)), dim3(256), 0,
+                               s_comp, g.vgeo, g.nvgeo, g.sgeo, g.vmapM, g.vmapP, g.elemtobndy, NQ,
+                               NQV, nreal, d_faceP, d_faceG, d_bad);
+        hipError_t le = hipGetLastError();
+        hipError_t ce = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s_comp);
+        hipError_t se = hipStreamSynchronize(s_comp);
+        hipFree(d_bad);
+        if (le != hipSuccess || ce != hipSuccess || se != hipSuccess)
+            return fail(CMDG_ERR_HIP, "cmdg_create: digest of the face tables failed");
+        if (bad & 1)
+            return fail(CMDG_ERR_INVALID, "cmdg_create: vmapM is not the face numbering of Grids.jl:586-594");
+        if (bad & 2)
+            return fail(CMDG_ERR_INVALID, "cmdg_create: sgeo's vMI differs from vgeo's MI at the face nodes (Grids.jl:1097-1101)");
+        if (bad & 4)
+            return fail(CMDG_ERR_INVALID, "cmdg_create: too many elements for 32-bit face indices");
+        g.faceP = d_faceP;
+        g.faceG = d_faceG;
     }
     aux = d->state_auxiliary;
     const size_t nd = (size_t)Np * nelem;
@@ -338,7 +368,8 @@ int EngineBase::halo_end(int s, double *array, int nvar)
 int EngineBase::rhs_segment(int seg, const RhsCtx &c)
 {
     const bool comm = communicate() && !(stacked && direction == DIR_VERTICAL);  // (:104-108)
-    const bool grad = ngf > 0 || nhyp > 0;
+    const bool gfl = gf_live();  // is state_gradient_flux read by anybody?
+    const bool grad = gfl || nhyp > 0;
     const bool hyper = nhyp > 0;
     int r;
 #define TRY(x) \
@@ -360,13 +391,13 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
                 TRY(flow_deviation(c.Qin, nreal / hooks.nvertelem, nghost / hooks.nvertelem));
         }
         launch_gradients(c, d_exterior, nexterior);
-        if (gradient_filter && ngf > 0) TRY(filter_apply(gradient_filter, gf, ngf));  // (:185-193)
+        if (gradient_filter && gfl) TRY(filter_apply(gradient_filter, gf, ngf));  // (:185-193)
         if (comm) {
-            if (ngf > 0) TRY(halo_begin(SLOT_GF, gf, ngf));
+            if (gfl) TRY(halo_begin(SLOT_GF, gf, ngf));
             if (hyper) TRY(halo_begin(SLOT_HG, hypgrad, 3 * ngl));
         }
         // update_auxiliary_state_gradient!(realelems)  (DGModel.jl:210-222)
-        if (has_hooks && ngf > 0) TRY(run_gradient_hooks(c, 0, nreal));
+        if (has_hooks && gfl) TRY(run_gradient_hooks(c, 0, nreal));
         if (hyper) launch_divgrad(c, d_interior, ninterior);
         break;
     case 2:
@@ -387,7 +418,7 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
     case 4:
         if (comm) {
             if (grad) {
-                if (ngf > 0) {
+                if (gfl) {
                     TRY(halo_end(SLOT_GF, gf, ngf));
                     // update_auxiliary_state_gradient!(ghostelems)  (DGModel.jl:355-361)
                     if (has_hooks) TRY(run_gradient_hooks(c, nreal, nelem));
@@ -1028,6 +1059,17 @@ int cmdg_synchronize(cmdg_handle h)
     if (!h) return CMDG_ERR_INVALID;
     DevGuard guard_(h->eng);
     return set_err(h, h->eng->synchronize());
+}
+
+int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value)
+{
+    if (!h) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
+    EngineBase *e = h->eng;
+    switch (option) {
+    case CMDG_OPT_KEEP_GRADFLUX: e->keep_gradflux = value != 0; return CMDG_OK;
+    default: return set_err(h, e->fail(CMDG_ERR_INVALID, "cmdg_set_option: unknown option"));
+    }
 }
 
 int cmdg_halo_begin(cmdg_handle h, double *array, int32_t nstate)

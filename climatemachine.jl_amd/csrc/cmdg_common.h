@@ -21,6 +21,16 @@ struct GridDev {
     const double *D;   // device, (Nq, Nq) column-major, horizontal
     const double *Dv;  // device, (Nqv, Nqv) column-major, vertical (== D for one order)
     int nvgeo;
+    // Face tables digested once at cmdg_create from the reference's (sgeo, vmap-, vmap+,
+    // elemtobndy), real elements only, indexed by the face task t = 0 .. NFT-1 of an element:
+    //   faceP[e][t]     int32, 0-based global node id of the plus side (eP * Np + vidP; the
+    //                   minus node itself on boundary faces, DGModel_kernels.jl:686-692)
+    //   faceG[e][c][t]  n1, n2, n3, sM (c = 0..3), one coalesced load per component
+    // vmap- is a pure function of (f, n) (checked at create) and vMI is MI of that node
+    // (Grids.jl:1097-1101, checked at create): neither is stored.  36 B per face node
+    // instead of the 56 B of the reference tables.
+    const int32_t *faceP;
+    const double *faceG;
 };
 
 // NQ = horizontal points per direction, NQV = vertical ones (polynomialorder = (N_h, N_v);

@@ -61,6 +61,8 @@ struct EngineBase {
     int64_t ninterior = 0, nexterior = 0;
     const uint8_t *d_activedofs = nullptr;
     double *d_D = nullptr;
+    int32_t *d_faceP = nullptr;  // digested face tables (GridDev::faceP / faceG)
+    double *d_faceG = nullptr;
     const int64_t *d_vmapsend = nullptr, *d_vmaprecv = nullptr;
     int64_t nvmapsend = 0, nvmaprecv = 0;
     std::vector<int> nabrtorank;
@@ -104,6 +106,13 @@ struct EngineBase {
     virtual void launch_tendency(const RhsCtx &c, const int64_t *elems, int64_t n) = 0;
     virtual void launch_update_aux(const RhsCtx &c, int64_t e0, int64_t e1) = 0;
     virtual bool has_update_aux() const = 0;
+    virtual bool law_needs_gradflux() const = 0;
+    bool keep_gradflux = false;  // CMDG_OPT_KEEP_GRADFLUX
+    // is state_gradient_flux formed (and exchanged) by an evaluation?
+    bool gf_live() const
+    {
+        return ngf > 0 && (keep_gradflux || law_needs_gradflux() || has_hooks || gradient_filter);
+    }
     virtual bool fused_update_aux() const = 0;
     virtual int init_derived() = 0;
     // mode 0: per-element minimum node distance, mode 1: per-element maximum Courant number
@@ -215,8 +224,12 @@ struct EngineT : EngineBase {
     {
         if (n <= 0) return;
         prof_begin(CMDG_K_GRADIENTS, s_comp);
-        hipLaunchKernelGGL((k_gradients<P, NQ_, NQV_>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0,
-                           s_comp, make_args(c, elems, n, diffusion_direction));
+        if (gf_live())
+            hipLaunchKernelGGL((k_gradients<P, NQ_, NQV_, true>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0,
+                               s_comp, make_args(c, elems, n, diffusion_direction));
+        else
+            hipLaunchKernelGGL((k_gradients<P, NQ_, NQV_, false>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0,
+                               s_comp, make_args(c, elems, n, diffusion_direction));
         prof_end(s_comp);
     }
     void launch_divgrad(const RhsCtx &c, const int64_t *elems, int64_t n) override
@@ -285,6 +298,7 @@ struct EngineT : EngineBase {
         return CMDG_OK;
     }
     bool has_update_aux() const override { return P::HAS_UPDATE_AUX && P::update_aux_active(prm); }
+    bool law_needs_gradflux() const override { return P::needs_gradflux(prm); }
     bool fused_update_aux() const override { return P::HAS_UPDATE_AUX && P::FUSE_UPDATE_AUX; }
     int init_derived() override
     {

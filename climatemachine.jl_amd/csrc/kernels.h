@@ -62,59 +62,107 @@ struct FacePt {
     int vidM, vidP, bctag;
 };
 
+// Volume node of face node n of face f: faces 1..6 = xi1-, xi1+, xi2-, xi2+, xi3-, xi3+, the
+// remaining two indices in order, lower axis fastest (Grids.jl:586-594).  This is vmap- minus
+// the element offset; cmdg_create checks the caller's vmap- against it.
+template <int NQ, int NQV = NQ>
+__host__ __device__ __forceinline__ constexpr int face_vid(int f, int n)
+{
+    const int a = n % NQ, b = n / NQ;
+    switch (f) {
+    case 0: return NQ * (a + NQ * b);
+    case 1: return (NQ - 1) + NQ * (a + NQ * b);
+    case 2: return a + NQ * NQ * b;
+    case 3: return a + NQ * ((NQ - 1) + NQ * b);
+    case 4: return n;
+    default: return n + NQ * NQ * (NQV - 1);
+    }
+}
+
 // index half of face_setup: issued at kernel start so that the plus-side gathers do not wait
 // for a dependent table load when the interface phase begins
 template <int NQ, int NQV = NQ>
-__device__ __forceinline__ void face_index(const GridDev &g, int64_t e, int f, int n, int64_t &idM,
-                                           int64_t &idP, int &bctag)
+__device__ __forceinline__ void face_index(const GridDev &g, int64_t e, int t, int f, int32_t &idP,
+                                           int &bctag)
 {
-    constexpr int Nfp = KDims<NQ, NQV>::Nfp;
-    const int64_t o = n + (int64_t)Nfp * (f + 6 * e);
-    idM = g.vmapM[o];
-    idP = g.vmapP[o];
+    idP = g.faceP[(int64_t)KDims<NQ, NQV>::NFT * e + t];
     bctag = (int)g.elemtobndy[f + 6 * e];
 }
 template <int NQ, int NQV = NQ>
-__device__ __forceinline__ void face_geometry(const GridDev &g, int64_t e, int f, int n,
-                                              int64_t idM, int64_t idP, int bctag, FacePt &fp)
+__device__ __forceinline__ void face_geometry(const GridDev &g, int64_t e, int t, int f, int n,
+                                              int32_t idP, int bctag, FacePt &fp)
 {
-    constexpr int Np = KDims<NQ, NQV>::Np, Nfp = KDims<NQ, NQV>::Nfp;
-    const int64_t o = n + (int64_t)Nfp * (f + 6 * e);
-    const double *sg = g.sgeo + 5 * o;
-    fp.n[0] = sg[SN1];
-    fp.n[1] = sg[SN2];
-    fp.n[2] = sg[SN3];
-    fp.sM = sg[SSM];
-    fp.vMI = sg[SVMI];
+    constexpr int Np = KDims<NQ, NQV>::Np, NFT = KDims<NQ, NQV>::NFT;
+    const double *sg = g.faceG + (int64_t)4 * NFT * e + t;
+    fp.n[0] = sg[0];
+    fp.n[1] = sg[NFT];
+    fp.n[2] = sg[2 * NFT];
+    fp.sM = sg[3 * NFT];
+    fp.vidM = face_vid<NQ, NQV>(f, n);
+    fp.vMI = g.vgeo[fp.vidM + (int64_t)Np * (VMI + (int64_t)g.nvgeo * e)];
     fp.bctag = bctag;
-    fp.eP = (idP - 1) / Np;
-    fp.vidM = (int)((idM - 1) % Np);
-    fp.vidP = (int)((idP - 1) % Np);
-    if (bctag != 0) {  // DGModel_kernels.jl:686-692
-        fp.eP = e;
-        fp.vidP = fp.vidM;
-    }
+    fp.eP = idP / Np;
+    fp.vidP = idP - (int)fp.eP * Np;
 }
 template <int NQ, int NQV = NQ>
-__device__ __forceinline__ void face_setup(const GridDev &g, int64_t e, int f, int n, FacePt &fp)
+__device__ __forceinline__ void face_setup(const GridDev &g, int64_t e, int t, int f, int n,
+                                           FacePt &fp)
 {
-    constexpr int Np = KDims<NQ, NQV>::Np, Nfp = KDims<NQ, NQV>::Nfp;
-    const int64_t o = n + (int64_t)Nfp * (f + 6 * e);
-    const double *sg = g.sgeo + 5 * o;
-    fp.n[0] = sg[SN1];
-    fp.n[1] = sg[SN2];
-    fp.n[2] = sg[SN3];
-    fp.sM = sg[SSM];
-    fp.vMI = sg[SVMI];
-    fp.bctag = (int)g.elemtobndy[f + 6 * e];
-    const int64_t idM = g.vmapM[o], idP = g.vmapP[o];
-    fp.eP = (idP - 1) / Np;
-    fp.vidM = (int)((idM - 1) % Np);
-    fp.vidP = (int)((idP - 1) % Np);
-    if (fp.bctag != 0) {  // DGModel_kernels.jl:686-692
-        fp.eP = e;
-        fp.vidP = fp.vidM;
+    int32_t idP;
+    int bctag;
+    face_index<NQ, NQV>(g, e, t, f, idP, bctag);
+    face_geometry<NQ, NQV>(g, e, t, f, n, idP, bctag, fp);
+}
+
+// One-time digest of the reference face tables (see GridDev); bad[0] collects what does not
+// hold: bit 0 vmap- is not the canonical face numbering, bit 1 sgeo's vMI is not vgeo's MI at
+// the face node, bit 2 a plus-side id does not fit 32 bits.
+static __global__ void k_face_digest(const double *__restrict__ vgeo, int nvgeo,
+                                     const double *__restrict__ sgeo,
+                                     const int64_t *__restrict__ vmapM,
+                                     const int64_t *__restrict__ vmapP,
+                                     const int64_t *__restrict__ elemtobndy, int NQ, int NQV,
+                                     int64_t nreal, int32_t *__restrict__ faceP,
+                                     double *__restrict__ faceG, int *__restrict__ bad)
+{
+    const int Np = NQ * NQ * NQV, Nfph = NQ * NQV, Nfpv = NQ * NQ;
+    const int Nfp = Nfph > Nfpv ? Nfph : Nfpv, NFT = 4 * Nfph + 2 * Nfpv;
+    const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= nreal * NFT) return;
+    const int64_t e = I / NFT;
+    const int t = (int)(I % NFT);
+    int f, n;
+    if (t < 4 * Nfph) {
+        f = t / Nfph;
+        n = t % Nfph;
+    } else {
+        f = 4 + (t - 4 * Nfph) / Nfpv;
+        n = (t - 4 * Nfph) % Nfpv;
     }
+    const int64_t o = n + (int64_t)Nfp * (f + 6 * e);
+    const int a = n % NQ, b = n / NQ;
+    int vid;
+    switch (f) {
+    case 0: vid = NQ * (a + NQ * b); break;
+    case 1: vid = (NQ - 1) + NQ * (a + NQ * b); break;
+    case 2: vid = a + NQ * NQ * b; break;
+    case 3: vid = a + NQ * ((NQ - 1) + NQ * b); break;
+    case 4: vid = n; break;
+    default: vid = n + NQ * NQ * (NQV - 1); break;
+    }
+    int flags = 0;
+    const int64_t idM = vmapM[o] - 1;
+    if (idM != e * Np + vid) flags |= 1;
+    int64_t idP = vmapP[o] - 1;
+    if (elemtobndy[f + 6 * e] != 0) idP = e * Np + vid;  // DGModel_kernels.jl:686-692
+    if (idP < 0 || idP > 2147483647LL) flags |= 4;
+    faceP[I] = (int32_t)idP;
+    const double *sg = sgeo + 5 * o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) faceG[((int64_t)4 * e + c) * NFT + t] = sg[c];
+    const double mi = vgeo[vid + (int64_t)Np * (VMI + (int64_t)nvgeo * e)];
+    if (!(sg[SVMI] == mi)) flags |= 2;
+    if (flags) atomicOr(bad, flags);
 }
 
 // A law may offer flux_first_order and wavespeed of one state in one call (both need the same
@@ -256,14 +304,14 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
     // viscosity (Held-Suarez) tau = -2*0*S and D_t = 0: the 9 fields only ever multiply
     // zeros, so the host picks the instantiation that does not read them (identical results).
     constexpr bool use_gf = NGF > 0 && USE_GF;
-    int64_t f_idM = 1, f_idP = 1;
+    int32_t f_idP = 0;
     int f_bctag = 0;
     bool face_on;
     {
         int f_f = 0, f_n = 0;
         KD::face_task(tid, f_f, f_n);
         face_on = tid < KD::NFT && (f_f < 4 ? hz : vt);
-        if (face_on) face_index<NQ, NQV>(a.g, e, f_f, f_n, f_idM, f_idP, f_bctag);
+        if (face_on) face_index<NQ, NQV>(a.g, e, tid, f_f, f_idP, f_bctag);
     }
     Vec<NS> S;
     double MI = 0;
@@ -394,7 +442,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
         if (face_on) {
             const int facedir = f < 4 ? DIR_HORIZONTAL : DIR_VERTICAL;
             FacePt fp;
-            face_geometry<NQ, NQV>(a.g, e, f, n, f_idM, f_idP, f_bctag, fp);
+            face_geometry<NQ, NQV>(a.g, e, tid, f, n, f_idP, f_bctag, fp);
             Vec<NS> QM, QPn, QPd, flux;
             Vec<NAUX> auxM, auxPn, auxPd;
             Vec<NGF> gfM, gfP;
@@ -512,12 +560,25 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
 
 // ---------------------------------------------------------------------------------
 // Gradient pass: volume_gradients! (:934-1328) + dgsem_interface_gradients! (:1365-1651)
-template <class P, int NQ, int NQV = NQ>
+// USE_GF = false: the law's second-order flux does not read the gradient-flux state (zero
+// viscosity): only the gradients the hyperdiffusion passes consume are formed and stored, and
+// state_gradient_flux is left untouched (cmdg_set_option(CMDG_OPT_KEEP_GRADFLUX) restores it).
+template <class P, bool USE_GF>
+__host__ __device__ constexpr unsigned gradient_argument_mask()
+{
+    if (USE_GF) return ~0u;
+    unsigned m = 0;
+    for (int s = 0; s < P::NGL; ++s) m |= 1u << P::hv_indexmap(s);
+    return m;
+}
+
+template <class P, int NQ, int NQV = NQ, bool USE_GF = true>
 __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? CMDG_GRAD_MINW : 1)) k_gradients(const PassArgs<P> a)
 {
     using KD = KDims<NQ, NQV>;
     constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGRAD = P::NGRAD,
-                  NGF = P::NGF, NGL = P::NGL, NHG = 3 * NGL, NACC = NGF + NHG;
+                  NGF = USE_GF ? P::NGF : 0, NGL = P::NGL, NHG = 3 * NGL, NACC = NGF + NHG;
+    constexpr unsigned GMASK = gradient_argument_mask<P, USE_GF>();
     __shared__ double sD[NQ * NQ + (NQV == NQ ? 0 : NQV * NQV)];
     const double *const sDv = sD + (NQV == NQ ? 0 : NQ * NQ);  // vertical derivative matrix
     __shared__ double sG[(NGRAD > 0 ? NGRAD : 1) * Np];
@@ -547,7 +608,8 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? C
         G.negzero();
         P::gradient_argument(a.prm, G, lQ, laux, a.t);
 #pragma unroll
-        for (int s = 0; s < NGRAD; ++s) sG[s * Np + tid] = G[s];
+        for (int s = 0; s < NGRAD; ++s)
+            if (GMASK >> s & 1) sG[s * Np + tid] = G[s];
     }
     __syncthreads();
     if (tid < Np) {
@@ -561,6 +623,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? C
             const double x21 = vg[XI2X1 * Np], x22 = vg[XI2X2 * Np], x23 = vg[XI2X3 * Np];
 #pragma unroll
             for (int s = 0; s < NGRAD; ++s) {
+                if (!(GMASK >> s & 1)) continue;
                 double G1 = 0.0, G2 = 0.0;
 #pragma unroll
                 for (int n = 0; n < NQ; ++n) {
@@ -579,6 +642,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? C
             const double x31 = vg[XI3X1 * Np], x32 = vg[XI3X2 * Np], x33 = vg[XI3X3 * Np];
 #pragma unroll
             for (int s = 0; s < NGRAD; ++s) {
+                if (!(GMASK >> s & 1)) continue;
                 double G3 = -0.0;
 #pragma unroll
                 for (int n = 0; n < NQV; ++n)
@@ -616,14 +680,15 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? C
         const bool on = f < 4 ? hz : vt;
         if (on) {
             FacePt fp;
-            face_setup<NQ, NQV>(a.g, e, f, n, fp);
+            face_setup<NQ, NQV>(a.g, e, tid, f, n, fp);
             Vec<NS> QM, QP;
             Vec<NAUX> auxM, auxP;
             Vec<NGRAD> GM, GP;
             load_state<NS, Np>(QM, a.Q, fp.vidM, e);       // only kept if the law reads them
             load_state<NAUX, Np>(auxM, a.aux, fp.vidM, e);  // (gradient_flux / boundary_state)
 #pragma unroll
-            for (int s = 0; s < NGRAD; ++s) GM[s] = sG[s * Np + fp.vidM];  // == G(Q-, aux-)
+            for (int s = 0; s < NGRAD; ++s)
+                GM[s] = (GMASK >> s & 1) ? sG[s * Np + fp.vidM] : 0.0;  // == G(Q-, aux-)
             load_state<NS, Np>(QP, a.Q, fp.vidP, fp.eP);
             load_state<NAUX, Np>(auxP, a.aux, fp.vidP, fp.eP);
             GP.negzero();
@@ -687,7 +752,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? C
     if (tid < Np) {
 #pragma unroll
         for (int s = 0; s < NGF; ++s)
-            a.gf[tid + (int64_t)Np * (s + (int64_t)NGF * e)] = sA[s * Np + tid];
+            a.gf[tid + (int64_t)Np * (s + (int64_t)P::NGF * e)] = sA[s * Np + tid];
 #pragma unroll
         for (int s = 0; s < NHG; ++s)
             a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)] = sA[(NGF + s) * Np + tid];
@@ -721,17 +786,24 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT)) k_divgrad(const PassArgs
         const double *vg = a.g.vgeo + (int64_t)Np * a.g.nvgeo * e + tid;
         const double M = vg[VM * Np];
         MI = vg[VMI * Np];
-        const double x11 = vg[XI1X1 * Np], x12 = vg[XI1X2 * Np], x13 = vg[XI1X3 * Np];
-        const double x21 = vg[XI2X1 * Np], x22 = vg[XI2X2 * Np], x23 = vg[XI2X3 * Np];
-        const double x31 = vg[XI3X1 * Np], x32 = vg[XI3X2 * Np], x33 = vg[XI3X3 * Np];
+        // only the metric rows of the directions this pass differentiates in are read (a
+        // horizontal diffusion_direction, Held-Suarez, never touches xi3)
+        double x11 = 0, x12 = 0, x13 = 0, x21 = 0, x22 = 0, x23 = 0, x31 = 0, x32 = 0, x33 = 0;
+        if (hz) {
+            x11 = vg[XI1X1 * Np], x12 = vg[XI1X2 * Np], x13 = vg[XI1X3 * Np];
+            x21 = vg[XI2X1 * Np], x22 = vg[XI2X2 * Np], x23 = vg[XI2X3 * Np];
+        }
+        if (vt) x31 = vg[XI3X1 * Np], x32 = vg[XI3X2 * Np], x33 = vg[XI3X3 * Np];
 #pragma unroll
         for (int s = 0; s < NGL; ++s) {
             const double G1 = a.hypgrad[tid + (int64_t)Np * (3 * s + 0 + (int64_t)NHG * e)];
             const double G2 = a.hypgrad[tid + (int64_t)Np * (3 * s + 1 + (int64_t)NHG * e)];
             const double G3 = a.hypgrad[tid + (int64_t)Np * (3 * s + 2 + (int64_t)NHG * e)];
-            sC[(0 * NG + s) * Np + tid] = M * (x11 * G1 + x12 * G2 + x13 * G3);
-            sC[(1 * NG + s) * Np + tid] = M * (x21 * G1 + x22 * G2 + x23 * G3);
-            sC[(2 * NG + s) * Np + tid] = M * (x31 * G1 + x32 * G2 + x33 * G3);
+            if (hz) {
+                sC[(0 * NG + s) * Np + tid] = M * (x11 * G1 + x12 * G2 + x13 * G3);
+                sC[(1 * NG + s) * Np + tid] = M * (x21 * G1 + x22 * G2 + x23 * G3);
+            }
+            if (vt) sC[(2 * NG + s) * Np + tid] = M * (x31 * G1 + x32 * G2 + x33 * G3);
             const int sidx = surf_index<NQ, NQV>(tid);
             if (sidx >= 0) {
                 sM[(3 * s + 0) * NSURF + sidx] = G1;
@@ -770,7 +842,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT)) k_divgrad(const PassArgs
         const bool on = f < 4 ? hz : vt;
         if (on) {
             FacePt fp;
-            face_setup<NQ, NQV>(a.g, e, f, n, fp);
+            face_setup<NQ, NQV>(a.g, e, tid, f, n, fp);
             Vec<NHG> gM, gP;
             const int sidx = surf_index<NQ, NQV>(fp.vidM);
 #pragma unroll
@@ -898,7 +970,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_LAP_MINW) k_gradlap
         const bool on = f < 4 ? hz : vt;
         if (on) {
             FacePt fp;
-            face_setup<NQ, NQV>(a.g, e, f, n, fp);
+            face_setup<NQ, NQV>(a.g, e, tid, f, n, fp);
             Vec<NS> QM, QP;
             Vec<NAUX> auxM, auxP;
             Vec<NGL> lapM, lapP;

@@ -36,7 +36,7 @@ def _dev(a, device, dtype=None):
 class DGModel:
     def __init__(self, balance_law, grid, numerical_flux_first_order=RusanovNumericalFlux,
                  direction=EveryDirection, diffusion_direction=None, device="cuda:0",
-                 state_auxiliary=None):
+                 state_auxiliary=None, keep_gradient_flux=False):
         if not torch.cuda.is_available():
             raise _lib.CmdgError("DGModel needs a HIP device; there is no CPU fallback")
         L = _lib.lib()
@@ -119,6 +119,13 @@ class DGModel:
         _lib.check(L.cmdg_create(C.byref(d), C.byref(h)))
         self.handle = h
         self._desc = d
+        if keep_gradient_flux:
+            self.set_option(_lib.OPT_KEEP_GRADFLUX, 1)
+
+    def set_option(self, option, value):
+        """``cmdg_set_option``: ``_lib.OPT_KEEP_GRADFLUX`` = refresh ``state_gradient_flux`` in
+        every evaluation even when the law's fluxes never read it (zero viscosity)."""
+        _lib.check(self.L.cmdg_set_option(self.handle, int(option), int(value)), self.handle)
 
     def close(self):
         if getattr(self, "handle", None):

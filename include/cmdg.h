@@ -138,6 +138,16 @@ int cmdg_lsrk_run(cmdg_handle h, double *Q, double *dQ, double t, double dt, int
                   int32_t nstages, const double *rka, const double *rkb, const double *rkc);
 int cmdg_synchronize(cmdg_handle h);
 
+/* Options of a handle.
+ * CMDG_OPT_KEEP_GRADFLUX (default 0): a law whose second-order flux does not read the
+ *   gradient-flux state (the dry atmosphere with zero viscosity: tau = -2 nu S = 0) has the
+ *   nine columns of dg.state_gradient_flux neither formed, stored nor exchanged -- the tendency
+ *   is bit-identical without them.  1 restores the reference's behaviour of refreshing
+ *   state_gradient_flux in every evaluation (DGModel.jl:126-206), for callers that read it
+ *   (diagnostics, the diffusive Courant number). */
+enum { CMDG_OPT_KEEP_GRADFLUX = 1 };
+int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value);
+
 /* ---- halo (MPIStateArrays.jl:411-514, 837-871) -------------------------------- */
 /* begin_ghost_exchange!: pack face nodes of `array` (Np, nstate, nelem) and post the
  * sends/receives; end_ghost_exchange!: wait and unpack into the ghost elements. */

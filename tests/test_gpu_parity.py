@@ -308,15 +308,27 @@ def test_held_suarez_tendency_matches_oracle(cm, oracle, torch):
     torch.cuda.synchronize()
     dg(Tg, Q, 0.0, 1.0, 0.0)
     Tg = Tg.cpu().numpy()
+    # north star: L-inf relative < 1e-12 (observed on the device: 0 .. 2e-16, the kernels keep
+    # the reference's summation order and the forcing's pow/log agree to the last bit here)
     for s in range(5):
-        assert rel_linf(Tg[:nr, s], To[:nr, s]) < 1e-11, s    # cancellation-heavy: see below
-    for name, a, b in (("gf", dg.state_gradient_flux, odg.state_gradient_flux),
-                       ("hvdiv", dg.Qhypervisc_div, odg.Qhypervisc_div),
-                       ("hvgrad", dg.Qhypervisc_grad, odg.Qhypervisc_grad)):
+        assert rel_linf(Tg[:nr, s], To[:nr, s]) < TOL, s
+
+    def check_columns(name, a, b):
         a, b = a.cpu().numpy()[:nr], b[:nr]
         for s in range(b.shape[1]):
             if np.abs(b[:, s]).max() > 0:
-                assert rel_linf(a[:, s], b[:, s]) < 1e-9, (name, s)
+                assert rel_linf(a[:, s], b[:, s]) < TOL, (name, s)
+    check_columns("hvdiv", dg.Qhypervisc_div, odg.Qhypervisc_div)
+    check_columns("hvgrad", dg.Qhypervisc_grad, odg.Qhypervisc_grad)
+    # zero viscosity: tau = -2 nu S = 0, the gradient-flux state only ever multiplies zeros, so
+    # it is neither formed nor stored nor exchanged unless the caller asks for it
+    assert not dg.state_gradient_flux.any().item()
+    dg.set_option(cm._lib.OPT_KEEP_GRADFLUX, 1)
+    Tk = dg.create_state()
+    dg(Tk, Q, 0.0, 1.0, 0.0)
+    assert np.array_equal(Tk.cpu().numpy()[:nr], Tg[:nr])      # bit-identical tendency
+    check_columns("gf", dg.state_gradient_flux, odg.state_gradient_flux)
+    dg.set_option(cm._lib.OPT_KEEP_GRADFLUX, 0)
     # LSRK: 3 fused steps vs the oracle's unfused steps
     dt = 2.0
     solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
