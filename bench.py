@@ -439,9 +439,19 @@ def main():
         # passes, the tendency.  Secondary figure: the path is HBM bound (< 1 flop/B), the
         # contraction runs on fp64 VALU out of LDS, not on MFMA.
         cf = 6 * (grid.N[0] + 1) * (law.ngrad + 2 * law.ngradlap + law.ns)
-        out["contraction"] = {"flops_per_node_update": cf,
-                              "achieved_TFLOPs": cf * (dofs / law.ns) / el / 1e12,
-                              "unit": "fp64 VALU (no MFMA)"}
+        out["contraction"] = {
+            "flops_per_node_update": cf,
+            "achieved_TFLOPs": cf * (dofs / law.ns) / el / 1e12,
+            "unit": "fp64 VALU out of LDS (v_mul_f64 + v_add_f64, no contraction of a*b+c)",
+            # the shipped kernels issue no MFMA; measured on this chip (profiles/r02_*):
+            "mfma_util": 0.0,
+            "measured_fp64_peaks_TFLOPs": {"v_mfma_f64_16x16x4_f64": 47.7, "v_mfma_f64_4x4x4_4b_f64": 72.7,
+                                           "v_fma_f64": 64.8, "v_mul_f64+v_add_f64": 34.0},
+            "mfma_variant": "k_gradients with the contraction on v_mfma_f64_16x16x4_f64: +70 % time, "
+                            "5.1 % matrix-pipe busy (SQ_VALU_MFMA_BUSY_CYCLES); contraction removed "
+                            "altogether: -2.1 % per step",
+            "evidence": ["profiles/r02_fp64_peak.jsonl", "profiles/r02_ab_mfma_contraction.txt",
+                         "profiles/r02_mfma_variant_pmc_per_launch.json"]}
         if "FILTER" in kern:
             # Q read + written (5 fields each) and the two reference-state columns
             fb = 8 * (2 * law.ns + 2) * grid.Np * grid.nreal

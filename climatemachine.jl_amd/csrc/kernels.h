@@ -401,6 +401,10 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
             if (hz) {  // generic kernel called with HorizontalDirection() (:64-309)
                 double lt = 0.0;
                 if (a.direction == DIR_HORIZONTAL && P::HAS_SOURCE) lt += S[s];
+#ifdef CMDG_DBG_NOCONTRACT
+                lt += MI * sD[i] * sF[(0 * NS + s) * Np + tid] + MI * sD[j] * sF[(1 * NS + s) * Np + tid];
+                if (false)
+#endif
 #pragma unroll
                 for (int n = 0; n < NQ; ++n) {
                     lt += MI * sD[n + NQ * i] * sF[(0 * NS + s) * Np + n + NQ * (j + NQ * k)];
@@ -411,6 +415,10 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
             if (vt) {  // ::VerticalDirection kernel (:312-548); beta = true after the
                        // horizontal call in EveryDirection (SpaceDiscretization.jl:1192)
                 double lt = 0.0;
+#ifdef CMDG_DBG_NOCONTRACT
+                lt += MI * sDv[k] * sF[(2 * NS + s) * Np + tid] + S[s];
+                if (false)
+#endif
 #pragma unroll
                 for (int kk = 0; kk < NQV; ++kk) {
                     lt += MI * sDv[kk + NQV * k] * sF[(2 * NS + s) * Np + i + NQ * (j + NQ * kk)];
@@ -549,6 +557,8 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
             const int64_t o = tid + (int64_t)Np * (s + (int64_t)NS * e);
             const double T = sT[s * Np + tid];
             if constexpr (LSRK) {  // update!: Q += rkb*dt*dQ; dQ *= rka
+                // re-read (an L1/L2 hit) rather than ten more live registers: keeping the state
+                // costs a wave per SIMD (profiles/r02_ab_mfma_contraction.txt, "keepq")
                 a.Qout[o] = a.Q[o] + a.rkb_dt * T;
                 a.tendency[o] = T * a.rka_next;
             } else {
@@ -560,6 +570,58 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
 
 // ---------------------------------------------------------------------------------
 // Gradient pass: volume_gradients! (:934-1328) + dgsem_interface_gradients! (:1365-1651)
+#ifdef CMDG_MFMA_GRAD
+// A/B variant (not the default, see DESIGN.md "MFMA"): the (N+1)-point derivative contractions of
+// the gradient pass on the matrix pipe, v_mfma_f64_16x16x4_f64.  One 16x16x16 product (four
+// instructions) applies blockdiag(D, D, D) to 3 x 16 lines of five values: 48 lines, 2 400 useful
+// of 8 192 issued flops (K = 5 does not tile the instruction).  Lines of direction dir (0: xi1,
+// 1: xi2, 2: xi3) of the active fields are taken from sG and the derivatives land in
+// sDer[dir][field][node]; thread = node then applies the metric terms as the VALU path does.
+typedef double cmdg_v4d __attribute__((ext_vector_type(4)));
+template <int NFLD>
+__device__ __forceinline__ void mfma_line_derivatives(const double *sD, const double *sG,
+                                                      double *sDer, unsigned fldpack, int nact,
+                                                      int ndir, unsigned dirpack, int tid, int nthreads)
+{
+    constexpr int NQ = 5, Np = 125;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const int nlines = 25 * nact, ngroups = (nlines + 47) / 48;
+    const int c = lane & 15, kr = lane >> 4;
+    double Aop[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int ip = c, r = 4 * kk + kr;  // A[row ip][col r]
+        Aop[kk] = (ip < 15 && r < 15 && ip / 5 == r / 5) ? sD[(ip % 5) + NQ * (r % 5)] : 0.0;
+    }
+    for (int w = wave; w < ndir * ngroups; w += nwaves) {
+        const int dir = (dirpack >> (2 * (w / ngroups))) & 3, g = w % ngroups;
+        cmdg_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int r = 4 * kk + kr, L = 48 * g + 16 * (r / 5) + c, n = r % 5;
+            double b = 0.0;
+            if (r < 15 && L < nlines) {
+                const int aa = L % 25, s = (fldpack >> (4 * (L / 25))) & 15;
+                const int node = dir == 0 ? 5 * aa + n
+                                          : (dir == 1 ? (aa % 5) + 5 * n + 25 * (aa / 5) : aa + 25 * n);
+                b = sG[s * Np + node];
+            }
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[kk], b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int ip = kr + 4 * reg, L = 48 * g + 16 * (ip / 5) + c, i = ip % 5;
+            if (ip < 15 && L < nlines) {
+                const int aa = L % 25, s = (fldpack >> (4 * (L / 25))) & 15;
+                const int node = dir == 0 ? 5 * aa + i
+                                          : (dir == 1 ? (aa % 5) + 5 * i + 25 * (aa / 5) : aa + 25 * i);
+                sDer[(dir * NFLD + s) * Np + node] = acc[reg];
+            }
+        }
+    }
+}
+#endif
+
 // USE_GF = false: the law's second-order flux does not read the gradient-flux state (zero
 // viscosity): only the gradients the hyperdiffusion passes consume are formed and stored, and
 // state_gradient_flux is left untouched (cmdg_set_option(CMDG_OPT_KEEP_GRADFLUX) restores it).
@@ -583,6 +645,10 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? C
     const double *const sDv = sD + (NQV == NQ ? 0 : NQ * NQ);  // vertical derivative matrix
     __shared__ double sG[(NGRAD > 0 ? NGRAD : 1) * Np];
     __shared__ double sA[(NACC > 0 ? NACC : 1) * Np];  // [gf..., hypgrad...][ijk]
+#ifdef CMDG_MFMA_GRAD
+    constexpr bool MFMA = NQ == 5 && NQV == 5 && NGRAD > 0;
+    __shared__ double sDer[MFMA ? 3 * NGRAD * Np : 1];
+#endif
     const int tid = threadIdx.x;
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
     if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
@@ -612,6 +678,20 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? C
             if (GMASK >> s & 1) sG[s * Np + tid] = G[s];
     }
     __syncthreads();
+#ifdef CMDG_MFMA_GRAD
+    if constexpr (MFMA) {
+        static_assert(NGRAD <= 8, "field ordinals are packed four bits each");
+        unsigned fldpack = 0, dirpack = 0;  // active fields / directions, packed
+        int nact = 0, ndir = 0;
+#pragma unroll
+        for (int s = 0; s < NGRAD; ++s)
+            if (GMASK >> s & 1) fldpack |= (unsigned)s << (4 * nact++);
+        if (hz) dirpack |= 0u << (2 * ndir++), dirpack |= 1u << (2 * ndir++);
+        if (vt) dirpack |= 2u << (2 * ndir++);
+        mfma_line_derivatives<NGRAD>(sD, sG, sDer, fldpack, nact, ndir, dirpack, tid, KD::NT);
+        __syncthreads();
+    }
+#endif
     if (tid < Np) {
         const int i = tid % NQ, j = (tid / NQ) % NQ, k = tid / (NQ * NQ);
         const double *vg = a.g.vgeo + (int64_t)Np * a.g.nvgeo * e + tid;
@@ -625,6 +705,16 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? C
             for (int s = 0; s < NGRAD; ++s) {
                 if (!(GMASK >> s & 1)) continue;
                 double G1 = 0.0, G2 = 0.0;
+#if defined(CMDG_MFMA_GRAD)
+                if constexpr (MFMA) {
+                    G1 = sDer[(0 * NGRAD + s) * Np + tid];
+                    G2 = sDer[(1 * NGRAD + s) * Np + tid];
+                } else
+#elif defined(CMDG_DBG_NOCONTRACT)
+                // ablation: the contraction's share of the kernel (results are wrong)
+                G1 = sD[i] * sG[s * Np + tid], G2 = sD[j] * sG[s * Np + tid];
+                if (false)
+#endif
 #pragma unroll
                 for (int n = 0; n < NQ; ++n) {
                     G1 += sD[i + NQ * n] * sG[s * Np + n + NQ * (j + NQ * k)];
@@ -644,6 +734,14 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? C
             for (int s = 0; s < NGRAD; ++s) {
                 if (!(GMASK >> s & 1)) continue;
                 double G3 = -0.0;
+#if defined(CMDG_MFMA_GRAD)
+                if constexpr (MFMA) {
+                    G3 = sDer[(2 * NGRAD + s) * Np + tid];
+                } else
+#elif defined(CMDG_DBG_NOCONTRACT)
+                G3 = sDv[k] * sG[s * Np + tid];
+                if (false)
+#endif
 #pragma unroll
                 for (int n = 0; n < NQV; ++n)
                     G3 += sDv[k + NQV * n] * sG[s * Np + i + NQ * (j + NQ * n)];
