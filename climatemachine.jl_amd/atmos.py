@@ -358,10 +358,19 @@ class DryAtmosModel:
                    + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]))
             aux[:, self.off_turb, :] = 2 / (np.cbrt(det) * max(max(1, n) for n in grid.N))
         if self.tau_hyper is not None:
-            # lengthscale_horizontal (Geometry.jl:129-151): |dx/dxi_1|, |dx/dxi_2|
+            # lengthscale_horizontal (Geometry.jl:129-151): with invJ[i, j] = d xi_i / d x_j taken
+            # from the xi-x columns of vgeo (LocalGeometry, Geometry.jl:78-85),
+            #   Delta_1 = |invJ \ e_1| 2 / N_1,  Delta_2 = |invJ \ e_2| 2 / N_2.
+            # (Not the stored x-xi columns: in this snapshot Metrics.jl:617-667 fills them with
+            # adj * adj' / det, which is not the inverse, and nothing on this path reads them.
+            # tests/test_hyperdiffusion_cross_law.py would see the difference.)
             N = grid.N
-            c1 = np.sqrt(vg[:, G._x1xi1] ** 2 + vg[:, G._x2xi1] ** 2 + vg[:, G._x3xi1] ** 2)
-            c2 = np.sqrt(vg[:, G._x1xi2] ** 2 + vg[:, G._x2xi2] ** 2 + vg[:, G._x3xi2] ** 2)
+            invJ = np.stack([np.stack([vg[:, c] for c in row], axis=-1) for row in (
+                (G._xi1x1, G._xi1x2, G._xi1x3), (G._xi2x1, G._xi2x2, G._xi2x3),
+                (G._xi3x1, G._xi3x2, G._xi3x3))], axis=-2)          # (nelem, Np, 3, 3)
+            J = np.linalg.inv(invJ)
+            c1 = np.sqrt((J[..., :, 0] ** 2).sum(axis=-1))
+            c2 = np.sqrt((J[..., :, 1] ** 2).sum(axis=-1))
             aux[:, self.off_delta, :] = (c1 * 2 / N[0] + c2 * 2 / N[1]) / 2
         return aux
 

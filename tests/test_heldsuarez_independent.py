@@ -271,6 +271,17 @@ def test_drybiharmonic_coefficient(hs):
         assert np.abs(hyp - nu4 * gl).max() <= 4e-16 * np.abs(nu4 * gl).max()
 
 
+def test_horizontal_length_scale_is_a_node_spacing(hs):
+    """aux.hyperdiffusion.Delta = lengthscale_horizontal(geom) (Geometry.jl:129-151) is the local
+    average horizontal node distance: on the 6 x 2 x 2 cubed sphere with N = 4 about a quarter of
+    an element width, 2 pi r / (4 * 2) / 4 = 1.25e6 m, within the equiangular grid's distortion.
+    (A reading of the stored x-xi columns instead of the inverse of the xi-x ones gives 1e-5 m.)"""
+    _, law, grid, _, aux = hs
+    d = aux[:grid.nreal, law.off_delta, :]
+    nominal = 2 * np.pi * PLANET_RADIUS / (4 * 2) / 4
+    assert 0.6 * nominal < d.min() and d.max() < 1.6 * nominal, (d.min(), d.max(), nominal)
+
+
 def test_hyperdiffusion_gradient_argument_is_the_horizontal_velocity(hs):
     """u_h = (I - k k') u and h_tot = e_tot + R_d T (TurbulenceClosures.jl:875-889,
     AtmosModel.jl:625-690): gradient arguments 5..8 of the law."""
