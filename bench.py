@@ -61,7 +61,8 @@ def build_workload(cm, name, rank, size, ne, args, nhorz=None, nvert=None):
         n_horz = nhorz or args.nhorz or hs_nhorz(args.scaling, size)
         n_vert = nvert or args.nvert
         Rrange = np.linspace(ps.planet_radius, ps.planet_radius + 30e3, n_vert + 1)
-        topl = M.StackedCubedSphereTopology(n_horz, Rrange, boundary=(1, 2), rank=rank, size=size)
+        topl = M.StackedCubedSphereTopology(n_horz, Rrange, boundary=(1, 2), rank=rank, size=size,
+                                            connectivity=getattr(args, "connectivity", "full"))
         grid = M.DiscontinuousSpectralElementGrid(topl, 4,
                                                   meshwarp=M.equiangular_cubed_sphere_warp)
         law = A.DryAtmosModel(A.HeldSuarezSetup(ps), orientation=A.ORIENT_SPHERICAL,

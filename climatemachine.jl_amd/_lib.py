@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMDG_LIB", os.path.join(_HERE, "libcmdg.so"))   # CMDG_LIB: tuning builds
 
 CMDG_K = dict(GRADIENTS=0, DIVGRAD=1, GRADLAP=2, TENDENCY=3, PACK=4, UNPACK=5, UPDATE_AUX=6,
-              FILTER=7, STACK_INTEGRAL=8)
+              FILTER=7, STACK_INTEGRAL=8, TRANSPORT=9, HALO_EXPOSED=10)
 STACK_MAXOUT = 8
 OPT_KEEP_GRADFLUX = 1
 
@@ -95,6 +95,8 @@ SYMBOLS = [
     ("cmdg_set_option", C.c_int, [_vp, _i32, _i32]),
     ("cmdg_halo_begin", C.c_int, [_vp, _vp, _i32]),
     ("cmdg_halo_end", C.c_int, [_vp, _vp, _i32]),
+    ("cmdg_fillsendbuf", C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32]),
+    ("cmdg_transferrecvbuf", C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32]),
     ("cmdg_comm_unique_id", C.c_int, [_vp]),
     ("cmdg_comm_init_rccl", C.c_int, [_vp, _vp, _i32, _i32]),
     ("cmdg_comm_selftest", C.c_int, [_vp, _i64]),
@@ -145,6 +147,11 @@ def lib():
                 "g.build()'` -- there is no CPU fallback" % LIB_PATH)
         try:
             import torch  # noqa: F401  (loads libamdhip64 / librccl first)
+            # one RCCL instance per process: libcmdg resolves RCCL with dlopen and takes the
+            # copy torch.distributed uses (torch/lib/librccl.so) rather than a second one
+            rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if os.path.exists(rccl):
+                os.environ.setdefault("CMDG_RCCL_LIB", rccl)
         except Exception:
             pass
         L = C.CDLL(LIB_PATH)

@@ -43,7 +43,12 @@ constexpr int kDouble = 8;  // ncclFloat64 / ncclDouble
 static bool load(std::string &err)
 {
     if (lib) return true;
+    // one RCCL instance per process: the path the caller names (CMDG_RCCL_LIB, e.g. the copy
+    // torch ships and has loaded already), else whatever is loaded, else the system library
     const char *names[] = {"librccl.so.1", "librccl.so", nullptr};
+    if (const char *p = getenv("CMDG_RCCL_LIB"))
+        if (*p) lib = dlopen(p, RTLD_NOW | RTLD_GLOBAL);
+    for (int i = 0; names[i] && !lib; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
     for (int i = 0; names[i] && !lib; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
     if (!lib) {
         err = std::string("cannot load librccl: ") + dlerror();
@@ -245,6 +250,7 @@ void EngineBase::prof_begin(int kernel, hipStream_t st)
     if (!profiling) return;
     ProfRec r;
     r.kernel = kernel;
+    r.clamp = false;
     hipEventCreate(&r.e0);
     hipEventCreate(&r.e1);
     hipEventRecord(r.e0, st);
@@ -261,7 +267,7 @@ void EngineBase::prof_collect()
         hipEventSynchronize(r.e1);
         float ms = 0;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
-            prof_ms[r.kernel] += ms;
+            prof_ms[r.kernel] += r.clamp && ms < 0 ? 0.0f : ms;
             prof_n[r.kernel] += 1;
         }
         hipEventDestroy(r.e0);
@@ -272,6 +278,12 @@ void EngineBase::prof_collect()
 
 // ---- halo: begin_ghost_exchange! / end_ghost_exchange!  MPIStateArrays.jl:411-483 ----
 int EngineBase::halo_begin(int s, double *array, int nvar)
+{
+    if (int r = halo_pack(s, array, nvar)) return r;
+    return halo_post(&s, 1);
+}
+
+int EngineBase::halo_pack(int s, double *array, int nvar)
 {
     if (!communicate()) return CMDG_OK;
     if (transport == TRANSPORT_NONE)
@@ -296,26 +308,40 @@ int EngineBase::halo_begin(int s, double *array, int nvar)
         prof_end(s_comm);
     }
     HIPCHK(hipEventRecord(h.ev_packed, s_comm));
+    return CMDG_OK;
+}
+
+int EngineBase::halo_post(const int *slots, int nslots)
+{
+    if (!communicate()) return CMDG_OK;
     if (transport == TRANSPORT_RCCL) {
-        // one group per exchange: every neighbour pair has its own xGMI link
+        // one group for everything that begins here: every neighbour pair has its own xGMI
+        // link, and one group costs one RCCL launch however many arrays travel
+        prof_begin(CMDG_K_TRANSPORT, s_comm);
         if (rccl::GroupStart()) return fail(CMDG_ERR_COMM, "ncclGroupStart failed");
-        for (size_t n = 0; n < nabrtorank.size(); ++n) {
-            const int64_t r0 = nabrrecv[2 * n] - 1, rn = nabrrecv[2 * n + 1] - r0;
-            const int64_t s0 = nabrsend[2 * n] - 1, sn = nabrsend[2 * n + 1] - s0;
-            int rc = rccl::Recv(h.recvbuf + r0 * nvar, (size_t)(rn * nvar), rccl::kDouble,
-                                nabrtorank[n], nccl_comm, s_comm);
-            if (!rc)
-                rc = rccl::Send(h.sendbuf + s0 * nvar, (size_t)(sn * nvar), rccl::kDouble,
-                                nabrtorank[n], nccl_comm, s_comm);
-            if (rc) {
-                rccl::GroupEnd();
-                return fail(CMDG_ERR_COMM, std::string("ncclSend/Recv: ") + rccl::GetErrorString(rc));
+        for (int q = 0; q < nslots; ++q) {
+            HaloSlot &h = slot[slots[q]];
+            const int nvar = h.nvar;
+            for (size_t n = 0; n < nabrtorank.size(); ++n) {
+                const int64_t r0 = nabrrecv[2 * n] - 1, rn = nabrrecv[2 * n + 1] - r0;
+                const int64_t s0 = nabrsend[2 * n] - 1, sn = nabrsend[2 * n + 1] - s0;
+                int rc = rccl::Recv(h.recvbuf + r0 * nvar, (size_t)(rn * nvar), rccl::kDouble,
+                                    nabrtorank[n], nccl_comm, s_comm);
+                if (!rc)
+                    rc = rccl::Send(h.sendbuf + s0 * nvar, (size_t)(sn * nvar), rccl::kDouble,
+                                    nabrtorank[n], nccl_comm, s_comm);
+                if (rc) {
+                    rccl::GroupEnd();
+                    return fail(CMDG_ERR_COMM, std::string("ncclSend/Recv: ") + rccl::GetErrorString(rc));
+                }
             }
         }
         if (int rc = rccl::GroupEnd())
             return fail(CMDG_ERR_COMM, std::string("ncclGroupEnd: ") + rccl::GetErrorString(rc));
+        prof_end(s_comm);
     }
-    h.active = true;  // only now: a failure above leaves the slot free for the next call
+    // only now: a failure above leaves the slots free for the next call
+    for (int q = 0; q < nslots; ++q) slot[slots[q]].active = true;
     return CMDG_OK;
 }
 
@@ -343,9 +369,11 @@ int EngineBase::halo_end(int s, double *array, int nvar)
             const int64_t s0 = peer->nabrsend[2 * m] - 1, sn = peer->nabrsend[2 * m + 1] - s0;
             if (rn != sn) return fail(CMDG_ERR_COMM, "local transport: send/recv sizes differ");
             HIPCHK(hipStreamWaitEvent(s_comm, peer->slot[s].ev_packed, 0));
+            if (n == 0) prof_begin(CMDG_K_TRANSPORT, s_comm);
             HIPCHK(hipMemcpyAsync(h.recvbuf + r0 * nvar, peer->slot[s].sendbuf + s0 * nvar,
                                   sizeof(double) * rn * nvar, hipMemcpyDeviceToDevice, s_comm));
         }
+        if (!nabrtorank.empty()) prof_end(s_comm);
         HIPCHK(hipEventRecord(h.ev_pulled, s_comm));
     }
     if (nvmaprecv > 0) {
@@ -356,6 +384,18 @@ int EngineBase::halo_end(int s, double *array, int nvar)
         prof_end(s_comm);
     }
     HIPCHK(hipEventRecord(h.ev_done, s_comm));
+    if (profiling) {
+        // exposed time of this exchange: from the moment the compute stream has nothing left to
+        // do but wait (its interior launches are done) to the moment the ghosts are in place
+        ProfRec r;
+        r.kernel = CMDG_K_HALO_EXPOSED;
+        r.clamp = true;
+        hipEventCreate(&r.e0);
+        hipEventCreate(&r.e1);
+        hipEventRecord(r.e0, s_comp);
+        hipEventRecord(r.e1, s_comm);
+        prof.push_back(r);
+    }
     HIPCHK(hipStreamWaitEvent(s_comp, h.ev_done, 0));
     return CMDG_OK;
 }
@@ -392,9 +432,17 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
         }
         launch_gradients(c, d_exterior, nexterior);
         if (gradient_filter && gfl) TRY(filter_apply(gradient_filter, gf, ngf));  // (:185-193)
-        if (comm) {
-            if (gfl) TRY(halo_begin(SLOT_GF, gf, ngf));
-            if (hyper) TRY(halo_begin(SLOT_HG, hypgrad, 3 * ngl));
+        if (comm) {  // both begin here: packed back to back, posted in one group
+            int slots[2], ns_ = 0;
+            if (gfl) {
+                TRY(halo_pack(SLOT_GF, gf, ngf));
+                slots[ns_++] = SLOT_GF;
+            }
+            if (hyper) {
+                TRY(halo_pack(SLOT_HG, hypgrad, 3 * ngl));
+                slots[ns_++] = SLOT_HG;
+            }
+            if (ns_) TRY(halo_post(slots, ns_));
         }
         // update_auxiliary_state_gradient!(realelems)  (DGModel.jl:210-222)
         if (has_hooks && gfl) TRY(run_gradient_hooks(c, 0, nreal));
@@ -1083,6 +1131,28 @@ int cmdg_halo_end(cmdg_handle h, double *array, int32_t nstate)
     if (!h || !array) return CMDG_ERR_INVALID;
     DevGuard guard_(h->eng);
     return set_err(h, h->eng->halo_end(SLOT_Q, array, nstate));
+}
+
+int cmdg_fillsendbuf(double *sendbuf, const double *buf, const int64_t *vmapsend, int64_t nvmap,
+                     int32_t Np, int32_t nstate)
+{
+    if (!sendbuf || !buf || !vmapsend || nvmap < 0 || Np < 1 || nstate < 1) return CMDG_ERR_INVALID;
+    if (nvmap == 0) return CMDG_OK;
+    const int64_t n = nvmap * nstate;
+    hipLaunchKernelGGL(k_fillsendbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, sendbuf, buf,
+                       vmapsend, nvmap, Np, nstate);
+    return hipGetLastError() == hipSuccess && hipStreamSynchronize(0) == hipSuccess ? CMDG_OK : CMDG_ERR_HIP;
+}
+
+int cmdg_transferrecvbuf(double *buf, const double *recvbuf, const int64_t *vmaprecv,
+                         int64_t nvmap, int32_t Np, int32_t nstate)
+{
+    if (!buf || !recvbuf || !vmaprecv || nvmap < 0 || Np < 1 || nstate < 1) return CMDG_ERR_INVALID;
+    if (nvmap == 0) return CMDG_OK;
+    const int64_t n = nvmap * nstate;
+    hipLaunchKernelGGL(k_transferrecvbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, buf,
+                       recvbuf, vmaprecv, nvmap, Np, nstate);
+    return hipGetLastError() == hipSuccess && hipStreamSynchronize(0) == hipSuccess ? CMDG_OK : CMDG_ERR_HIP;
 }
 
 int cmdg_comm_unique_id(void *out128)

@@ -48,6 +48,7 @@ struct FilterObj {
 struct ProfRec {
     int kernel;
     hipEvent_t e0, e1;
+    bool clamp;  // record max(0, elapsed): e1 may precede e0 (exposed halo time)
 };
 
 struct EngineBase {
@@ -126,6 +127,10 @@ struct EngineBase {
     int lsrk_step(double *Q, double *dQ, double t, double dt, int nstages, const double *rka,
                   const double *rkb, const double *rkc);
     int halo_begin(int s, double *array, int nvar);
+    // begin_ghost_exchange! in two halves, so that exchanges that begin at the same point of an
+    // evaluation are packed one after the other and posted in ONE RCCL group
+    int halo_pack(int s, double *array, int nvar);
+    int halo_post(const int *slots, int nslots);
     int halo_end(int s, double *array, int nvar);
     void abort_exchanges();  // after a failed call: no exchange is left "begun"
     int ensure_work();

@@ -293,6 +293,15 @@ class DGModel:
         hs = [f.handle if f is not None else None for f in fs]
         _lib.check(self.L.cmdg_set_filters(self.handle, *hs), self.handle)
 
+    def halo_begin(self, array):
+        """``begin_ghost_exchange!(array)`` (MPIStateArrays.jl:411-442) of a state-like array."""
+        self._torch_ready()
+        _lib.check(self.L.cmdg_halo_begin(self.handle, array.data_ptr(), array.shape[1]), self.handle)
+
+    def halo_end(self, array):
+        """``end_ghost_exchange!(array)`` (MPIStateArrays.jl:451-483)."""
+        _lib.check(self.L.cmdg_halo_end(self.handle, array.data_ptr(), array.shape[1]), self.handle)
+
     def comm_init_rccl(self, unique_id, rank, nranks):
         """``unique_id``: the 128 bytes of ``rccl_unique_id()`` made on rank 0."""
         _lib.check(self.L.cmdg_comm_init_rccl(self.handle, bytes(unique_id), int(rank),

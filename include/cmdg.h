@@ -153,6 +153,16 @@ int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value);
  * sends/receives; end_ghost_exchange!: wait and unpack into the ghost elements. */
 int cmdg_halo_begin(cmdg_handle h, double *array, int32_t nstate);
 int cmdg_halo_end(cmdg_handle h, double *array, int32_t nstate);
+/* kernel_fillsendbuf! / kernel_transferrecvbuf! (MPIStateArrays.jl:837-871) on their own, for
+ * arrays of any (Np, nstate): sendbuf (nstate, nvmap) state-fastest <- buf (Np, nstate, nelem)
+ * at the 1-based linear node ids vmapsend[i] = n + Np (e - 1), and the inverse into the ghost
+ * elements.  Device pointers; runs on the null stream and returns when done.  (The handle-based
+ * exchange above launches the same kernels; these entries let the reference's known-answer
+ * test, test/Arrays/mpi_comm.jl:23-153, be replayed on them.) */
+int cmdg_fillsendbuf(double *sendbuf, const double *buf, const int64_t *vmapsend, int64_t nvmap,
+                     int32_t Np, int32_t nstate);
+int cmdg_transferrecvbuf(double *buf, const double *recvbuf, const int64_t *vmaprecv,
+                         int64_t nvmap, int32_t Np, int32_t nstate);
 /* Transport set-up.  Multi-process: RCCL point-to-point; `unique_id` is the 128-byte
  * ncclUniqueId made by cmdg_comm_unique_id on rank 0 and broadcast by the caller. */
 int cmdg_comm_unique_id(void *out128);
@@ -381,7 +391,11 @@ int cmdg_group_split_explicit_step(cmdg_handle *slow, cmdg_handle *fast, int32_t
 enum {
     CMDG_K_GRADIENTS = 0, CMDG_K_DIVGRAD = 1, CMDG_K_GRADLAP = 2, CMDG_K_TENDENCY = 3,
     CMDG_K_PACK = 4, CMDG_K_UNPACK = 5, CMDG_K_UPDATE_AUX = 6, CMDG_K_FILTER = 7,
-    CMDG_K_STACK_INTEGRAL = 8, CMDG_K_COUNT = 9
+    CMDG_K_STACK_INTEGRAL = 8,
+    /* halo: the transport between pack and unpack (RCCL group or device copies) on the halo
+     * stream, and the time the compute stream had to wait for an exchange to finish (the part of
+     * an exchange NOT hidden behind interior work; one record per exchange, zero when hidden) */
+    CMDG_K_TRANSPORT = 9, CMDG_K_HALO_EXPOSED = 10, CMDG_K_COUNT = 11
 };
 /* bracket every launch with HIP events on the launch stream (off by default) */
 int cmdg_profile_enable(cmdg_handle h, int32_t on);

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""How much of the ghost exchange is NOT hidden behind interior work, measured on one GPU.
+
+One rank of the 8-rank Held-Suarez partition (its real elements, ghosts, interior / exterior
+lists and per-neighbour ranges exactly as on an 8-GPU node) runs with the RCCL transport and every
+neighbour mapped to the rank itself: message sizes, the number of send / receive pairs per group,
+pack / unpack kernels, the second stream and the event choreography are the real ones; what is
+not real is the wire (an RCCL self-copy instead of xGMI), so the transport time below is a lower
+bound.  HIP events: CMDG_K_TRANSPORT brackets each RCCL group on the halo stream,
+CMDG_K_HALO_EXPOSED is the time the compute stream had nothing left to do but wait for an
+exchange (zero when the exchange finished behind the interior kernels).
+
+    python scripts/measure_halo_exposure.py [--scaling weak|strong] [--rank R] [--steps K]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong", "weak-small"])
+    ap.add_argument("--size", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--nvert", type=int, default=8)
+    ap.add_argument("--nhorz", type=int, default=0)
+    args = ap.parse_args()
+    # face-connected ghosts: what a neighbour sends is what it receives (the vertex-connected
+    # default of the stacked topologies lists a few hundred extra nodes on one side only)
+    args.connectivity = "face"
+    import torch
+    from cmdg_loader import cm
+    law, grid, direction, dt, desc = bench.build_workload(cm, "heldsuarez", args.rank, args.size, 0, args)
+    nn = len(grid.nabrtorank)
+    send = np.asarray(grid.nabrtovmapsend).reshape(nn, 2)
+    recv = np.asarray(grid.nabrtovmaprecv).reshape(nn, 2)
+    sym = all(send[n][1] - send[n][0] == recv[n][1] - recv[n][0] for n in range(nn))
+    if not sym:
+        raise SystemExit("send / receive ranges differ per neighbour: cannot talk to oneself")
+    real_nbrs = list(grid.nabrtorank)
+    grid.nabrtorank = [0] * nn
+    dg = cm.dgmodel.DGModel(law, grid, direction=direction[0], diffusion_direction=direction[1])
+    dg.comm_init_rccl(cm.dgmodel.rccl_unique_id(), 0, 1)
+    Q = dg.init_ode_state(0.0)
+    solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+    solver.dostep(Q, nsteps=5)
+    dg.synchronize()
+    t0 = time.perf_counter()
+    solver.dostep(Q, nsteps=args.steps)
+    dg.synchronize()
+    el = time.perf_counter() - t0
+    dg.profile_reset()
+    dg.profile_enable(True)
+    solver.dostep(Q, nsteps=args.steps)
+    dg.synchronize()
+    dg.profile_enable(False)
+    out = {"workload": desc["workload"], "rank": args.rank, "of": args.size,
+           "real_elements": int(grid.nreal), "ghost_elements": int(grid.nelem - grid.nreal),
+           "interior_elements": int(len(grid.interiorelems)), "exterior_elements": int(len(grid.exteriorelems)),
+           "neighbours": real_nbrs, "send_nodes_per_neighbour": [int(s[1] - s[0] + 1) for s in send],
+           "bytes_per_exchange_per_state_column": int(8 * len(grid.vmapsend)),
+           "ms_per_step": 1e3 * el / args.steps, "steps": args.steps, "kernels": {}}
+    for k in ("GRADIENTS", "DIVGRAD", "GRADLAP", "TENDENCY", "PACK", "TRANSPORT", "UNPACK", "HALO_EXPOSED"):
+        ms, n = dg.profile_get(k)
+        if n:
+            out["kernels"][k] = {"avg_us": 1e3 * ms / n, "launches": n, "total_ms_per_step": ms / args.steps}
+    ex = out["kernels"].get("HALO_EXPOSED")
+    if ex:
+        out["exposed_ms_per_step"] = ex["total_ms_per_step"]
+        out["exposed_fraction_of_step"] = ex["total_ms_per_step"] / out["ms_per_step"]
+        out["exchanges_per_stage"] = ex["launches"] / (5 * args.steps)
+    print(json.dumps(out))
+    dg.close()
+
+
+if __name__ == "__main__":
+    main()
