@@ -65,6 +65,8 @@ class CmdgRhsHooks(C.Structure):
         ("nvertelem", C.c_int32), ("Imat", C.c_void_p),
         ("has_flow_deviation", C.c_int32), ("flow_u_col", C.c_int32), ("flow_ud_col", C.c_int32),
         ("flow_H", C.c_double),
+        ("ops_before_gradients", C.c_int32), ("pre_rhs_handle", C.c_void_p),
+        ("pre_rhs_src_col", C.c_int32), ("pre_rhs_dst_aux_col", C.c_int32),
     ]
 
 

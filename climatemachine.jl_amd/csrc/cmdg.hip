@@ -93,6 +93,7 @@ EngineBase::~EngineBase()
     if (d_elemred) hipFree(d_elemred);
     if (d_Imat) hipFree(d_Imat);
     if (d_flowint) hipFree(d_flowint);
+    if (d_preT) hipFree(d_preT);
     if (d_Dv) hipFree(d_Dv);
     if (ev_comp) hipEventDestroy(ev_comp);
     if (nccl_comm && rccl::CommDestroy) rccl::CommDestroy(nccl_comm);
@@ -710,6 +711,17 @@ int EngineBase::set_hooks(const cmdg_rhs_hooks *hk)
             return fail(CMDG_ERR_INVALID, "hooks: flow deviation columns / depth");
         if (!d_flowint) HIPCHK(hipMalloc(&d_flowint, sizeof(double) * 2 * Np * nelem));
     }
+    if (hk->pre_rhs_handle) {
+        EngineBase *ch = hk->pre_rhs_handle->eng;
+        if (!ch || ch == this || ch->Np != Np || ch->nelem != nelem || ch->ns != ns || ch->dev != dev)
+            return fail(CMDG_ERR_INVALID, "hooks: the nested operator must share grid, state and device");
+        if (communicate() || ch->communicate())
+            return fail(CMDG_ERR_UNSUPPORTED, "hooks: a nested operator is single-rank only");
+        if (hk->pre_rhs_src_col < 0 || hk->pre_rhs_src_col >= ch->ns || hk->pre_rhs_dst_aux_col < 0 ||
+            hk->pre_rhs_dst_aux_col >= naux)
+            return fail(CMDG_ERR_INVALID, "hooks: nested operator column out of range");
+        if (!d_preT) HIPCHK(hipMalloc(&d_preT, sizeof(double) * (size_t)Np * ch->ns * nelem));
+    }
     if (hk->has_integral || hk->has_flow_deviation) {
         if (!hk->Imat) return fail(CMDG_ERR_INVALID, "hooks: Imat is NULL");
         if (!d_Imat) HIPCHK(hipMalloc(&d_Imat, sizeof(double) * NQ * NQ));
@@ -726,6 +738,27 @@ int EngineBase::run_pre_hooks(const RhsCtx &c)
     for (int i = 0; i < hooks.npre; ++i)
         if (int r = filter_apply(reinterpret_cast<const FilterObj *>(hooks.pre_filter[i]), c.Qin, ns))
             return r;
+    if (hooks.pre_rhs_handle) {
+        // conti3d_dg(ct3d_dQ, Q, p, t; increment = false); A.w = dQ.theta  (OceanModel.jl:456-477)
+        EngineBase *ch = hooks.pre_rhs_handle->eng;
+        HIPCHK(hipEventRecord(ev_comp, s_comp));
+        HIPCHK(hipStreamWaitEvent(ch->s_comp, ev_comp, 0));
+        RhsCtx cc;
+        cc.tendency = d_preT;
+        cc.Qin = c.Qin;
+        cc.t = c.t;
+        cc.alpha = 1.0;
+        cc.beta = 0.0;
+        if (int r = ch->rhs_async(cc)) return fail(r, "nested operator: " + ch->err);
+        HIPCHK(hipEventRecord(ch->ev_comp, ch->s_comp));
+        HIPCHK(hipStreamWaitEvent(s_comp, ch->ev_comp, 0));
+        const int64_t n = nreal * Np;
+        hipLaunchKernelGGL(k_scaled_column_copy, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)),
+                           dim3(256), 0, s_comp, aux, naux, hooks.pre_rhs_dst_aux_col, (const double *)d_preT,
+                           ch->ns, hooks.pre_rhs_src_col, 1.0, Np, (int64_t)0, nreal);
+    }
+    if (hooks.ops_before_gradients)
+        if (int r = run_column_ops(c, 0, nreal)) return r;
     if (hooks.has_flow_deviation)
         if (int r = flow_deviation(c.Qin, 0, nreal / hooks.nvertelem)) return r;
     return CMDG_OK;
@@ -774,6 +807,16 @@ int EngineBase::run_gradient_hooks(const RhsCtx &c, int64_t e0, int64_t e1)
         hipLaunchKernelGGL(k_scaled_column_copy, dim3(nb), dim3(256), 0, s_comp, aux, naux,
                            hooks.copy_aux_col[i], gf, ngf, hooks.copy_gf_col[i], hooks.copy_scale[i],
                            Np, e0, e1);
+    if (hooks.ops_before_gradients) return CMDG_OK;  // done in update_auxiliary_state! already
+    return run_column_ops(c, e0, e1);
+}
+
+// upward integral, downward integral, surface value down the column: elements [e0, e1)
+int EngineBase::run_column_ops(const RhsCtx &c, int64_t e0, int64_t e1)
+{
+    if (e1 <= e0) return CMDG_OK;
+    const int64_t n = (e1 - e0) * Np;
+    const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 65535);
     const int nv = hooks.nvertelem;
     if (hooks.has_integral)
         if (int r = stack_integral(false, c.Qin, ns, aux, naux, nv, nullptr, &hooks.integral, e0 / nv,
@@ -982,6 +1025,9 @@ int cmdg_physics_counts(int32_t physics_id, const int32_t *iparam, int32_t out[6
     case CMDG_PHYSICS_PRESSURE_GRADIENT: return counts_pgrad(iparam, out);
     case CMDG_PHYSICS_SHALLOW_WATER: return counts_sw(iparam, out);
     case CMDG_PHYSICS_MOIST_ATMOS: return counts_moist(iparam, out);
+    case CMDG_PHYSICS_OCEAN_SE01:
+    case CMDG_PHYSICS_CONTINUITY3D_SE01:
+    case CMDG_PHYSICS_BAROTROPIC_SE01: return counts_se01(physics_id, out);
     default: return CMDG_ERR_UNSUPPORTED;
     }
 }
@@ -1016,6 +1062,9 @@ int cmdg_create(const cmdg_desc *d, cmdg_handle *out)
     case CMDG_PHYSICS_PRESSURE_GRADIENT: e = make_engine_pgrad(d, err); break;
     case CMDG_PHYSICS_SHALLOW_WATER: e = make_engine_sw(d, err); break;
     case CMDG_PHYSICS_MOIST_ATMOS: e = make_engine_moist(d, err); break;
+    case CMDG_PHYSICS_OCEAN_SE01:
+    case CMDG_PHYSICS_CONTINUITY3D_SE01:
+    case CMDG_PHYSICS_BAROTROPIC_SE01: e = make_engine_se01(d, err); break;
     default: err = "unknown physics_id"; break;
     }
     if (!e) {

@@ -149,6 +149,8 @@ struct EngineBase {
                            int64_t nh = -1);
     int flow_deviation(double *Q, int64_t h0, int64_t nh);
     double *d_flowint = nullptr;  // (Np, 2, nelem) column integral of the horizontal velocity
+    double *d_preT = nullptr;     // tendency of the nested operator of the hooks (pre_rhs_handle)
+    int run_column_ops(const RhsCtx &c, int64_t e0, int64_t e1);
     int run_gradient_hooks(const RhsCtx &c, int64_t e0, int64_t e1);
     double *d_Imat = nullptr;
     double *d_Dv = nullptr;  // vertical derivative matrix when the vertical order differs
@@ -348,6 +350,8 @@ EngineBase *make_engine_moist(const cmdg_desc *d, std::string &err);
 int counts_moist(const int32_t *iparam, int32_t out[6]);
 int counts_sw(const int32_t *iparam, int32_t out[6]);
 EngineBase *make_engine_pgrad(const cmdg_desc *d, std::string &err);
+EngineBase *make_engine_se01(const cmdg_desc *d, std::string &err);
+int counts_se01(int32_t physics_id, int32_t out[6]);
 int counts_pgrad(const int32_t *iparam, int32_t out[6]);
 
 }  // namespace cmdg

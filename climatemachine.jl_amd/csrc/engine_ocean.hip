@@ -2,6 +2,7 @@
 // PressureGradientModel used by the reference-state initialisation (physics_pgrad.h).
 #include "engine.h"
 #include "physics_ocean.h"
+#include "physics_ocean01.h"
 #include "physics_pgrad.h"
 #include "physics_sw.h"
 
@@ -64,6 +65,47 @@ EngineBase *make_engine_sw(const cmdg_desc *d, std::string &err)
         err = "ShallowWaterModel: polynomial order not compiled in (have N = 2..5)";
         return nullptr;
     }
+}
+
+// src/Ocean/SplitExplicit01: OceanModel, Continuity3dModel, BarotropicModel (N = 4, the order
+// of its reference tests; the barotropic model also with two nodes along the extrusion)
+template <class P>
+static void se01_counts(int32_t out[6])
+{
+    out[0] = P::NS;
+    out[1] = P::NAUX;
+    out[2] = P::NGRAD;
+    out[3] = P::NGF;
+    out[4] = out[5] = 0;
+}
+int counts_se01(int32_t physics_id, int32_t out[6])
+{
+    switch (physics_id) {
+    case CMDG_PHYSICS_OCEAN_SE01: se01_counts<OceanSE01>(out); return CMDG_OK;
+    case CMDG_PHYSICS_CONTINUITY3D_SE01: se01_counts<Continuity3dSE01>(out); return CMDG_OK;
+    case CMDG_PHYSICS_BAROTROPIC_SE01: se01_counts<BarotropicSE01>(out); return CMDG_OK;
+    default: return CMDG_ERR_UNSUPPORTED;
+    }
+}
+
+EngineBase *make_engine_se01(const cmdg_desc *d, std::string &err)
+{
+    if (d->N[0] != 4) {
+        err = "SplitExplicit01 laws: polynomial order not compiled in (have N = 4)";
+        return nullptr;
+    }
+    if (d->physics_id == CMDG_PHYSICS_BAROTROPIC_SE01) {
+        if (d->N[2] == 1) return make_engine<BarotropicSE01, 5, 2>(d);
+        if (d->N[2] == 4) return make_engine<BarotropicSE01, 5>(d);
+        err = "BarotropicModel: extrusion order 1 or 4";
+        return nullptr;
+    }
+    if (d->N[2] != 4) {
+        err = "SplitExplicit01 laws: one polynomial order in all directions";
+        return nullptr;
+    }
+    if (d->physics_id == CMDG_PHYSICS_OCEAN_SE01) return make_engine<OceanSE01, 5>(d);
+    return make_engine<Continuity3dSE01, 5>(d);
 }
 
 int counts_pgrad(const int32_t *, int32_t out[6])

@@ -51,8 +51,13 @@ enum {
     CMDG_PHYSICS_PRESSURE_GRADIENT = 4, /* PressureGradientModel, ref_state.jl:196-233 */
     CMDG_PHYSICS_SHALLOW_WATER = 5,     /* ShallowWaterModel (barotropic half of the split-explicit
                                            ocean), on a one-layer extrusion of the 2-D grid */
-    CMDG_PHYSICS_MOIST_ATMOS = 6        /* AtmosModel LES configuration with EquilMoist
+    CMDG_PHYSICS_MOIST_ATMOS = 6,       /* AtmosModel LES configuration with EquilMoist
                                            (src/Atmos/Model/moisture.jl:70-115) */
+    /* the older split-explicit ocean, src/Ocean/SplitExplicit01: OceanModel, the
+     * Continuity3dModel its update_auxiliary_state! evaluates, and the BarotropicModel (on the
+     * one-layer extrusion of the 2-D grid) */
+    CMDG_PHYSICS_OCEAN_SE01 = 7, CMDG_PHYSICS_CONTINUITY3D_SE01 = 8,
+    CMDG_PHYSICS_BAROTROPIC_SE01 = 9
 };
 
 /* Construction record: the fields of `DGModel(balance_law, grid, nf1, nf2, nfgrad;
@@ -313,6 +318,17 @@ typedef struct cmdg_rhs_hooks {
      * Q[flow_u_col + c]), c = 0, 1 */
     int32_t has_flow_deviation, flow_u_col, flow_ud_col;
     double flow_H;
+    /* SplitExplicit01's OceanModel does everything in update_auxiliary_state!
+     * (src/Ocean/SplitExplicit01/OceanModel.jl:432-541), i.e. BEFORE the gradient pass, and takes
+     * the horizontal divergence from a DG operator of its own (Continuity3dModel):
+     *   pre filters; pre_rhs_handle (if not NULL) is evaluated on Q with increment = false and
+     *   column pre_rhs_src_col of its tendency goes to auxiliary column pre_rhs_dst_aux_col;
+     *   then, with ops_before_gradients != 0, the integral / reverse integral / surface
+     *   operations above run here instead of after the gradient pass; then the flow deviation.
+     * Single rank only (the nested operator would need its own ghost exchange). */
+    int32_t ops_before_gradients;
+    cmdg_handle pre_rhs_handle;
+    int32_t pre_rhs_src_col, pre_rhs_dst_aux_col;
 } cmdg_rhs_hooks;
 /* hooks == NULL clears them.  Filters must outlive their use. */
 int cmdg_set_rhs_hooks(cmdg_handle h, const cmdg_rhs_hooks *hooks);

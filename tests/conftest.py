@@ -23,3 +23,10 @@ def oracle():
     from oracle import oracle as O
     O.build()
     return O
+
+
+@pytest.fixture(scope="session")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "no HIP device: the product path has no CPU fallback"
+    return t
