@@ -5,9 +5,9 @@ ClimateMachine-style balance laws.  Import through
 ``mesh`` and ``balancelaws`` are host-only (numpy).  ``dgmodel`` / ``odesolvers``
 need torch (device memory) and ``libcmdg.so`` (the hand-written HIP kernels); they
 are imported lazily so that the host-side pieces work without a GPU."""
-from . import atmos, balancelaws, mesh, moist, ocean  # noqa: F401
+from . import atmos, balancelaws, mesh, moist, ocean, ocean01  # noqa: F401
 
-__all__ = ["mesh", "balancelaws", "atmos", "moist", "ocean", "dgmodel", "odesolvers"]
+__all__ = ["mesh", "balancelaws", "atmos", "moist", "ocean", "ocean01", "dgmodel", "odesolvers"]
 
 
 def __getattr__(name):

@@ -70,6 +70,12 @@ class CmdgRhsHooks(C.Structure):
     ]
 
 
+class CmdgOcean01Desc(C.Structure):
+    """``cmdg_ocean01_desc`` of include/cmdg.h."""
+    _fields_ = [("nvertelem", C.c_int32), ("H", C.c_double), ("Imat", C.c_void_p),
+                ("add_fast_substeps", C.c_int32)]
+
+
 class CmdgOceanCouplingDesc(C.Structure):
     """``cmdg_ocean_coupling_desc`` of include/cmdg.h."""
     _fields_ = [
@@ -120,6 +126,8 @@ SYMBOLS = [
     ("cmdg_ocean_initialize_states", C.c_int, [_vp, _vp, _vp]),
     ("cmdg_ocean_tendency_from_slow_to_fast", C.c_int, [_vp, _vp, _vp, _vp]),
     ("cmdg_ocean_reconcile_from_fast_to_slow", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    ("cmdg_split_explicit01_step", C.c_int,
+     [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i32, _vp, _vp, _vp]),
     ("cmdg_lsrk_update", C.c_int, [_vp, _vp, _vp, _d, _d]),
     ("cmdg_ls3n_step", C.c_int, [_vp, _vp, _vp, _vp, _d, _d, _i32, _vp, _vp, _vp]),
     ("cmdg_ssprk_step", C.c_int, [_vp, _vp, _vp, _vp, _d, _d, _i32, _vp, _vp, _vp]),

@@ -239,12 +239,13 @@ class DGModel:
             C.byref(d)), self.handle)
 
     def set_rhs_hooks(self, pre_filters=(), gradflux_to_aux=(), integral=None,
-                      reverse_integral=None, surface_to_column=(), flow_deviation=None):
+                      reverse_integral=None, surface_to_column=(), flow_deviation=None,
+                      pre_rhs=None, ops_before_gradients=False):
         """The composition a law's ``update_auxiliary_state!`` /
         ``update_auxiliary_state_gradient!`` overrides stand for (see ``cmdg_rhs_hooks`` in
         include/cmdg.h); ``set_rhs_hooks()`` with no arguments clears them."""
         if not (pre_filters or gradflux_to_aux or integral or reverse_integral
-                or surface_to_column or flow_deviation):
+                or surface_to_column or flow_deviation or pre_rhs):
             self._hooks = None
             _lib.check(self.L.cmdg_set_rhs_hooks(self.handle, None), self.handle)
             return
@@ -277,10 +278,14 @@ class DGModel:
             hk.has_flow_deviation = 1
             hk.flow_u_col, hk.flow_ud_col = int(flow_deviation[0]), int(flow_deviation[1])
             hk.flow_H = float(flow_deviation[2])
+        if pre_rhs:             # (nested DGModel, its tendency column, auxiliary column)
+            hk.pre_rhs_handle = pre_rhs[0].handle
+            hk.pre_rhs_src_col, hk.pre_rhs_dst_aux_col = int(pre_rhs[1]), int(pre_rhs[2])
+        hk.ops_before_gradients = int(bool(ops_before_gradients))
         hk.nvertelem = int(self.grid.topology.stacksize or 0)
         Imat = np.ascontiguousarray(np.asarray(self.grid.Imat[-1], dtype=np.float64).T)
         hk.Imat = Imat.ctypes.data
-        self._hooks = (hk, Imat, list(pre_filters))      # keep alive
+        self._hooks = (hk, Imat, list(pre_filters), pre_rhs)      # keep alive
         _lib.check(self.L.cmdg_set_rhs_hooks(self.handle, C.byref(hk)), self.handle)
 
     def set_filters(self, gradient_filter=None, tendency_filter=None, step_filter=None):

@@ -361,6 +361,27 @@ int cmdg_ocean_tendency_from_slow_to_fast(cmdg_handle slow, cmdg_handle fast,
 int cmdg_ocean_reconcile_from_fast_to_slow(cmdg_handle slow, cmdg_handle fast,
                                            const cmdg_ocean_coupling_desc *d, double *Q_slow,
                                            const double *Q_fast);
+/* ---- the older split-explicit ocean, src/Ocean/SplitExplicit01 -------------------------
+ * dostep!(Qvec, split::SplitExplicitLSRK2nSolver, param, time)
+ * (SplitExplicitLSRK2nMethod.jl:81-190) with the exchange functions of
+ * src/Ocean/SplitExplicit01/Communication.jl: per slow stage initialize_fast_state! (number and
+ * size of the barotropic sub-steps, averaging window), initialize_adjustment!, the slow
+ * right-hand side twice (increment = false for the barotropic forcing, increment = true for the
+ * stage), tendency_from_slow_to_fast!, update!, the sub-steps with cummulate_fast_solution!,
+ * reconcile_from_fast_to_slow!.  `slow` = CMDG_PHYSICS_OCEAN_SE01 with its hooks installed,
+ * `fast` = CMDG_PHYSICS_BAROTROPIC_SE01 on the one-layer extrusion of the 2-D grid.
+ * numImplSteps > 0 (implicit vertical diffusion, IVDCModel.jl) is not carried. */
+typedef struct cmdg_ocean01_desc {
+    int32_t nvertelem;          /* stack size of the slow grid */
+    double H;                   /* problem.H */
+    const double *Imat;         /* HOST (Nq, Nq) column-major vertical grid.Imat of the slow grid */
+    int32_t add_fast_substeps;  /* OceanModel.add_fast_substeps */
+} cmdg_ocean01_desc;
+int cmdg_split_explicit01_step(cmdg_handle slow, cmdg_handle fast, const cmdg_ocean01_desc *d,
+                               double *Q3, double *dQ3, double *dQ2fast, double *Q2, double *dQ2,
+                               double t, double dt, double dt_fast, int32_t nstages,
+                               const double *rka, const double *rkb, const double *rkc);
+
 /* update!() of the LSRK methods on the handle's real elements (LowStorageRungeKuttaMethod.jl:
  * 146-166): Q += rkb_dt * dQ; dQ *= rka_next */
 int cmdg_lsrk_update(cmdg_handle h, double *dQ, double *Q, double rka_next, double rkb_dt);

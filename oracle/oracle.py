@@ -78,6 +78,9 @@ def lib():
         if hasattr(_LIB, "orc_atmos_new"):
             _LIB.orc_atmos_new.restype = C.POINTER(_Physics)
             _LIB.orc_atmos_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        for name in ("orc_ocean_se01_new", "orc_conti3d_se01_new", "orc_baro_se01_new"):
+            getattr(_LIB, name).restype = C.POINTER(_Physics)
+            getattr(_LIB, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _LIB.orc_physics_free.argtypes = [C.POINTER(_Physics)]
         _LIB.orc_get_max_threads.restype = C.c_int
     return _LIB
@@ -129,7 +132,8 @@ class OraclePhysics:
         self._ip = np.ascontiguousarray(ip, dtype=np.int32)
         self._dp = np.ascontiguousarray(dp, dtype=np.float64)
         ctor = {1: "orc_advdiff_new", 2: "orc_atmos_new", 3: "orc_ocean_new",
-                4: "orc_pgrad_new", 5: "orc_sw_new", 6: "orc_moist_new"}[law.physics_id]
+                4: "orc_pgrad_new", 5: "orc_sw_new", 6: "orc_moist_new", 7: "orc_ocean_se01_new",
+                8: "orc_conti3d_se01_new", 9: "orc_baro_se01_new"}[law.physics_id]
         self.c = getattr(lib(), ctor)(_p(self._ip), _p(self._dp), int(nf_first))
         ph = self.c.contents
         if nf_first >= 2 and not ph.numerical_flux_law:
@@ -665,6 +669,148 @@ class SplitExplicitOracle:
                 self._v2(A2)[:, 3:5] = du[:, :, None, :]
                 self._v3(Q3)[:, :, 0:2] += du[:, None, :, None, :]
                 self._v3(Q3)[:, :, 2] = self._v2(Q2)[:, 0, 0, :][:, None, None, :]
+
+
+# ---- src/Ocean/SplitExplicit01 --------------------------------------------------------------
+def ocean01_hooks(dg, conti_dg, vert_filter, exp_filter):
+    """``update_auxiliary_state!(dg, ::OceanModel, Q, t, elems)`` of
+    src/Ocean/SplitExplicit01/OceanModel.jl:432-541 on ``dg`` (an OracleDGModel of the law):
+    vertical cutoff filter on u, exponential filter on theta; ``conti3d_dg`` evaluated on Q and
+    its theta tendency copied to A.w; upward integrals (w, -g alpha_T theta) -> (w, pkin),
+    downward integral of pkin, w at the surface -> wz0; u_d = u - (1 / H) int u."""
+    from types import SimpleNamespace
+    law, grid = dg.law, dg.grid
+    nv = grid.topology.stacksize
+    Nqh = grid.Nq[0] * grid.Nq[1]
+
+    class _T:
+        target_id = 0
+
+        def __init__(self, idx):
+            self.indices = tuple(idx)
+
+        def aux_offsets(self):
+            return (0, 0)
+
+    ilaw = integral_fields_law([(0, 0), (1, 3)], [1.0, -(law.grav * law.alpha_T)], [0, 1], [1, 1],
+                               [1, 1], 4, 8)
+    rlaw = integral_fields_law([(0, 1)], [1.0], [1], [1], [1], 4, 8)
+    vlaw = integral_fields_law([(0, 0), (0, 1)], [1.0, 1.0], [0, 1], [0, 1], [0, 1], 4, 2)
+    dg._ocean_keep = SimpleNamespace(ilaw=ilaw, rlaw=rlaw, vlaw=vlaw, conti=conti_dg)
+    dg.integral_aux = np.zeros((grid.nelem, 2, grid.Np))
+    dg.conti3d_Q = np.zeros((grid.nelem, 4, grid.Np))
+
+    def integrate_velocity(X):
+        """FlowIntegralModel / TendencyIntegralModel (VerticalIntegralModel.jl): the upward
+        column integral of X's first two columns; value at the top of every stack (nh, 2, Nqh)."""
+        ia = dg.integral_aux
+        ia[:, 0, :], ia[:, 1, :] = X[:, 0, :], X[:, 1, :]
+        indefinite_stack_integral(vlaw, dg.og, X, ia)
+        return ia.reshape(grid.nelem // nv, nv, 2, grid.Nq[2], Nqh)[:, -1, :, -1, :]
+
+    dg.integrate_velocity = integrate_velocity
+
+    def pre(dgm, Q, t, which):
+        if which != "real":
+            return
+        A = dgm.state_auxiliary
+        apply_filter(Q, _T((1, 2)), grid, vert_filter, direction=VERTICAL)
+        apply_filter(Q, _T((4,)), grid, exp_filter, direction=VERTICAL)
+        conti_dg(dg.conti3d_Q, Q, t, 1.0, 0.0)            # increment = false
+        A[:grid.nreal, 0, :] = dg.conti3d_Q[:grid.nreal, 3, :]
+        indefinite_stack_integral(ilaw, dgm.og, Q, A)
+        reverse_indefinite_stack_integral(rlaw, dgm.og, Q, A)
+        data = A.reshape(grid.nelem // nv, nv, 8, grid.Nq[2], Nqh)
+        data[:, :, 2, :, :] = data[:, -1, 0, -1, :][:, None, None, :]       # wz0
+        top = integrate_velocity(Q)
+        Q5 = Q.reshape(grid.nelem // nv, nv, 4, grid.Nq[2], Nqh)
+        for c in (0, 1):                                                   # u_d
+            data[:, :, 3 + c] = Q5[:, :, c] - (top[:, c] / law.problem.H)[:, None, None, :]
+
+    dg.update_auxiliary_state_hook = pre
+
+
+class SplitExplicit01Oracle:
+    """``dostep!(Qvec, split::SplitExplicitLSRK2nSolver, param, time)``
+    (src/Ocean/SplitExplicit01/SplitExplicitLSRK2nMethod.jl:81-190) with the exchange functions of
+    src/Ocean/SplitExplicit01/Communication.jl; ``dg3`` carries ``ocean01_hooks``, ``dg2`` is
+    the BarotropicModel on the one-layer extrusion of the 2-D grid, both LSRK54."""
+
+    def __init__(self, dg3, dg2, Q3, Q2, dt_slow, dt_fast):
+        self.dg3, self.dg2, self.dt, self.dt_fast = dg3, dg2, float(dt_slow), float(dt_fast)
+        self.dQ3 = np.zeros_like(Q3)
+        self.dQ2fast = np.full_like(Q3, -0.0)
+        self.dQ2 = np.zeros_like(Q2)
+        g3, g2 = dg3.grid, dg2.grid
+        self.nv = g3.topology.stacksize
+        self.nh = g3.nelem // self.nv
+        self.Nqh = g3.Nq[0] * g3.Nq[1]
+        self.Nqk3, self.Nqk2 = g3.Nq[2], g2.Nq[2]
+        self.H = dg3.law.problem.H
+        self.add = int(dg3.law.add_fast_substeps)
+
+    def _v3(self, a):
+        return a.reshape(self.nh, self.nv, a.shape[1], self.Nqk3, self.Nqh)
+
+    def _v2(self, a):
+        return a.reshape(self.nh, a.shape[1], self.Nqk2, self.Nqh)
+
+    def dostep(self, Q3, Q2, time):
+        dg3, dg2, H = self.dg3, self.dg2, self.H
+        A3, A2 = dg3.state_auxiliary, dg2.state_auxiliary
+        ns = len(RKA)
+        # 2-D auxiliary columns: G_U 0:2, U_c 2:4, eta_c 4, U_s 5:7, eta_s 7, Delta_u 8:10,
+        # eta_diag 10, Delta_eta 11; 2-D state U 0:2, eta 2; 3-D auxiliary dG_u 5:7
+        for s in range(ns):
+            first, last = s == 0, s == ns - 1
+            ts = time + RKC[s] * self.dt
+            fract_dt = ((1 - RKC[s]) if last else (RKC[s + 1] - RKC[s])) * self.dt
+            # initialize_fast_state!
+            if self.add == 0:
+                steps = int(np.ceil(fract_dt / self.dt_fast)) if self.dt_fast > 0 else 1
+                fs1 = fs2 = fs3 = steps
+            else:
+                steps = int(np.ceil(fract_dt / self.dt_fast / self.add)) if self.dt_fast > 0 else 1
+                fs2, fs1, fs3 = self.add * steps, (self.add - 1) * steps, (self.add + 1) * steps
+            fdt = fract_dt / fs2
+            count = 0.0
+            A2[:, 2:5, :] = -0.0
+            if not first:
+                Q2[:, 2, :] = A2[:, 7, :]
+                Q2[:, 0:2, :] = A2[:, 5:7, :]
+            A3[:, 5:7, :] = 0.0                                  # initialize_adjustment!
+            dg3(self.dQ2fast, Q3, ts, 1.0, 0.0)                  # increment = false
+            top = dg3.integrate_velocity(self.dQ2fast)           # tendency_from_slow_to_fast!
+            self._v2(A2)[:, 0:2] = top[:, :, None, :]
+            self._v3(A3)[:, :, 5:7] = (-top / H)[:, None, :, None, :]
+            dg3(self.dQ3, Q3, ts, 1.0, 1.0)                      # increment = true
+            n = dg3.grid.nreal * Q3.shape[1] * Q3.shape[2]
+            lib().orc_lsrk_update(_p(self.dQ3), _p(Q3), C.c_double(RKA[(s + 1) % ns]),
+                                  C.c_double(RKB[s]), C.c_double(self.dt), C.c_int64(n))
+            for sub in range(1, fs3 + 1):
+                lsrk_step(dg2, Q2, self.dQ2, ts + (sub - 1) * fdt, fdt, RKA, RKB, RKC)
+                if sub >= fs1:                                   # cummulate_fast_solution!
+                    A2[:, 2:4, :] += Q2[:, 0:2, :]
+                    A2[:, 4, :] += Q2[:, 2, :]
+                    count += 1.0
+                if sub == fs2:
+                    A2[:, 5:7, :] = Q2[:, 0:2, :]
+                    A2[:, 7, :] = Q2[:, 2, :]
+            # reconcile_from_fast_to_slow!
+            A2[:, 2:5, :] *= 1 / count
+            top = dg3.integrate_velocity(Q3)
+            du = self._v2(A2)[:, 2:4, 0, :].copy()
+            du -= top
+            du /= H
+            self._v2(A2)[:, 8:10] = du[:, :, None, :]
+            self._v3(Q3)[:, :, 0:2] += du[:, None, :, None, :]
+            if last:
+                flat_eta = self._v3(Q3)[:, -1, 2, -1, :]
+                self._v2(A2)[:, 10] = flat_eta[:, None, :]
+                A2[:, 11, :] = A2[:, 4, :] - A2[:, 10, :]
+                self._v3(Q3)[:, :, 2] = self._v2(A2)[:, 4, 0, :][:, None, None, :]
+                Q2[:, 2, :] = A2[:, 7, :]
+                Q2[:, 0:2, :] = A2[:, 5:7, :]
 
 
 # ---- element filters (filter_oracle.c) --------------------------------------------------

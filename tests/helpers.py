@@ -399,3 +399,41 @@ def bomex_setup(nx=4, ny=4, nz=8, N=4, rank=0, size=1, zmax=3000.0, L=None):
                                   boundary=((0, 0), (0, 0), (1, 2)), rank=rank, size=size)
     grid = M.DiscontinuousSpectralElementGrid(topl, N)
     return MO.bomex_model(zmax), grid
+
+
+def simple_box_2dt_setup(Nx=20, Ny=20, Nz=20, N=4, N_extrusion=1):
+    """test/Ocean/SplitExplicit/simple_box_2dt.jl:478-517: 4e6 m x 4e6 m x 1000 m box, wind
+    stress 0.2 Pa, surface relaxation 20 m / day towards 10 (1 - y / Ly), no-slip coasts and
+    floor (tags 1, 2), stress + forcing surface (tag 3), c_h = 1, grav from CLIMAParameters,
+    add_fast_substeps = 2; slow step 5400 s, fast step 240 s, five days."""
+    O1, O = cm.ocean01, cm.ocean
+    Lx, Ly, H = 4e6, 4e6, 1000.0
+    problem = O1.SimpleBox01(Lx, Ly, H, tau_o=2e-1, lambda_r=20 / 86400, theta_E=10.0)
+    model = O1.OceanModel01(problem, grav=9.81, c_h=1.0, add_fast_substeps=2)
+    baro = O1.BarotropicModel01(model)
+    x, y, z = np.linspace(0.0, Lx, Nx + 1), np.linspace(0.0, Ly, Ny + 1), np.linspace(-H, 0.0, Nz + 1)
+    topl = M.StackedBrickTopology([x, y, z], periodicity=(False, False, False),
+                                  boundary=((1, 1), (1, 1), (2, 3)))
+    grid3 = M.DiscontinuousSpectralElementGrid(topl, N)
+    grid2 = O.extruded_barotropic_grid(x, y, N, periodicity=(False, False),
+                                       boundary=((1, 1), (1, 1)), N_extrusion=N_extrusion)
+    return model, grid3, baro, grid2
+
+
+def simple_box_2dt_fields(Q3, A3, Q2, A2, grid2):
+    """The 28 rows of test/Ocean/refvals/simple_box_2dt_refvals.jl; 2-D arrays on the k = 0
+    plane of the one-layer extrusion."""
+    O1 = cm.ocean01
+    Nqh = grid2.Nq[0] * grid2.Nq[1]
+    q0 = np.asarray(Q2).reshape(grid2.nelem, Q2.shape[1], grid2.Nq[2], Nqh)[:grid2.nreal, :, 0, :]
+    a0 = np.asarray(A2).reshape(grid2.nelem, A2.shape[1], grid2.Nq[2], Nqh)[:grid2.nreal, :, 0, :]
+    f = {}
+    for i, n in enumerate(O1.STATE_NAMES_3D):
+        f[("oce Q_3D", n)] = Q3[:, i]
+    for i, n in enumerate(O1.AUX_NAMES_3D):
+        f[("oce aux", n)] = A3[:, i]
+    for i, n in enumerate(O1.STATE_NAMES_2D):
+        f[("baro Q_2D", n)] = q0[:, i]
+    for i, n in enumerate(O1.AUX_NAMES_2D):
+        f[("baro aux", n)] = a0[:, i]
+    return f

@@ -1,0 +1,69 @@
+"""src/Ocean/SplitExplicit01 on the device through ``cmdg_split_explicit01_step``: step-by-step
+agreement with the oracle on a small box, and the reference's own regression -- test/Ocean/
+SplitExplicit/simple_box_2dt.jl: 20 x 20 x 20 elements, N = 4, eighty slow steps of 5400 s (five
+days) with 240 s barotropic sub-steps and the fast-step averaging window -- against the StateCheck
+table test/Ocean/refvals/simple_box_2dt_refvals.jl (28 fields x min / max / mean / std, 12 digits
+except where the reference itself asks for 8 - 10)."""
+import numpy as np
+import pytest
+
+from helpers import (check_split_explicit_table, simple_box_2dt_fields, simple_box_2dt_setup)
+from test_split_explicit01_oracle import GOLD, oracle_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_pair(cm, model, g3, baro, g2):
+    odg = cm.ocean01.OceanDGModel01(model, g3)
+    dg2 = cm.dgmodel.DGModel(baro, g2)
+    return odg, dg2
+
+
+def _scaled(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_slow_steps_match_oracle(cm, oracle, torch):
+    model, g3, baro, g2 = simple_box_2dt_setup(3, 3, 3)
+    o3, o2 = oracle_pair(oracle, model, g3, baro, g2)
+    Q3 = model.init_state_prognostic(g3, o3.state_auxiliary, 0.0)
+    Q2 = baro.init_state_prognostic(g2, o2.state_auxiliary, 0.0)
+    odg, dg2 = _device_pair(cm, model, g3, baro, g2)
+    Q3g, Q2g = odg.dg.init_ode_state(0.0), dg2.init_ode_state(0.0)
+    assert np.array_equal(Q3g.cpu().numpy(), Q3)
+    se_o = oracle.SplitExplicit01Oracle(o3, o2, Q3, Q2, 5400.0, 240.0)
+    se = cm.ocean01.SplitExplicitLSRK2nSolver01(odg, dg2, Q3g, Q2g, 5400.0, 240.0)
+    for s in range(2):
+        se_o.dostep(Q3, Q2, s * 5400.0)
+    se.dostep(Q3g, Q2g, 2)
+    A3g, A2g = odg.dg.state_auxiliary.cpu().numpy(), dg2.state_auxiliary.cpu().numpy()
+    A3, A2 = o3.state_auxiliary, o2.state_auxiliary
+    q3, q2 = Q3g.cpu().numpy(), Q2g.cpu().numpy()
+    for s in range(4):
+        assert _scaled(q3[:, s], Q3[:, s]) < 1e-11, ("Q3", s)
+    for s in range(3):
+        assert _scaled(q2[:, s], Q2[:, s]) < 1e-11, ("Q2", s)
+    for s in range(8):
+        assert _scaled(A3g[:, s], A3[:, s]) < 1e-10, ("A3", s)       # w, wz0: differences of u
+    for s in range(13):
+        assert _scaled(A2g[:, s], A2[:, s]) < 1e-10, ("A2", s)
+    odg.close()
+    dg2.close()
+
+
+def test_simple_box_2dt_reference_table(cm, torch):
+    model, g3, baro, g2 = simple_box_2dt_setup()
+    odg, dg2 = _device_pair(cm, model, g3, baro, g2)
+    Q3g, Q2g = odg.dg.init_ode_state(0.0), dg2.init_ode_state(0.0)
+    runtime, dt_slow = 5 * 24 * 3600.0, 5400.0
+    n = int(np.ceil(runtime / dt_slow))
+    se = cm.ocean01.SplitExplicitLSRK2nSolver01(odg, dg2, Q3g, Q2g, runtime / n, 240.0)
+    se.dostep(Q3g, Q2g, n)
+    assert se.steps == 80
+    nr = g3.nreal
+    f = simple_box_2dt_fields(Q3g.cpu().numpy()[:nr], odg.dg.state_auxiliary.cpu().numpy()[:nr],
+                              Q2g.cpu().numpy(), dg2.state_auxiliary.cpu().numpy(), g2)
+    worst = check_split_explicit_table(GOLD["varr"], GOLD["parr"], f, slack=2.0)
+    print("worst deviation in units of the reference's stated digit: %.2f" % worst)
+    odg.close()
+    dg2.close()
