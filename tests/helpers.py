@@ -340,6 +340,58 @@ def check_split_explicit_table(table, parr, fields, slack=2.0):
     return worst
 
 
+def scdocheck_match(cur, ref, pcmp):
+    """The acceptance rule of the reference's ``scdocheck`` (src/Diagnostics/Debug/StateCheck.jl:
+    404-452), character for character: both numbers printed with ``%28.20e``; equal exponents,
+    then the characters 2 .. pcmp + 4 (sign, leading digit, point, digits) compared left to right;
+    failing that, ``round(log10(relative difference)) < -pcmp``.  Returns the number of matching
+    characters (>= pcmp passes)."""
+    import math
+    cv, rv = "%28.20e" % cur, "%28.20e" % ref
+    nmatch = 0
+    if cv[24:28] == rv[24:28]:
+        for a, b in zip(cv[1:pcmp + 4], rv[1:pcmp + 4]):
+            if a != b:
+                break
+            nmatch += 1
+    if nmatch < pcmp and cur != ref:
+        e = round(math.log10(abs((ref - cur) / ref))) if ref != 0 else round(math.log10(abs(ref - cur)))
+        if e < -pcmp:
+            nmatch = int(-e)
+    return nmatch
+
+
+def check_statecheck_table(table, parr, fields, relaxed=None, report=None):
+    """Every row of a reference StateCheck table under the reference's own rule
+    (:func:`scdocheck_match`); ``relaxed[(array, field)]`` lowers the required digits of a row
+    (documented where used).  Returns (worst relative deviation in units of the stated digit,
+    fewest matching characters beyond the requirement); ``report`` (a list) receives one line per
+    statistic."""
+    worst, margin, bad = 0.0, 99, []
+    for row, prow in zip(table, parr):
+        key = (row[0], row[1])
+        assert key == (prow[0], prow[1])
+        got = statecheck(fields[key])
+        for j in range(4):
+            p = int(prow[2 + j])
+            if p == 0:
+                continue
+            if relaxed and key in relaxed:
+                p = min(p, relaxed[key])
+            ref = row[2 + j]
+            n = scdocheck_match(got[j], ref, p)
+            rel = abs(got[j] - ref) / abs(ref) if ref != 0 else abs(got[j])
+            if report is not None:
+                report.append("%-10s %-8s %-4s digits %2d of %2d  rel %.1e" % (
+                    key[0], key[1], ("min", "max", "mean", "std")[j], n, p, rel))
+            if n < p:
+                bad.append((key, ("min", "max", "mean", "std")[j], got[j], ref, n, p))
+            margin = min(margin, n - p)
+            worst = max(worst, rel * 10.0 ** p)
+    assert not bad, bad
+    return worst, margin
+
+
 def mms_atmos_setup(level=1, N=4):
     """test/Numerics/DGMethods/compressible_Navier_Stokes/mms_bc_atmos.jl, dim = 3: unit cube,
     (4 * 2^(level-1))^3 elements, warped (:252-262), every face InitStateBC; dry AtmosModel with
