@@ -49,11 +49,15 @@ struct MoistAtmos {
     static constexpr int NUPD = 4;
     __host__ __device__ static constexpr int upd_aux(int i) { return OMOIST + i; }
     static constexpr int NDER = 0;
-    // minus-side auxiliary fields of the interface kernels: Phi, grad Phi, ref p, ref rho, Delta
-    static constexpr int NFAUX = 7;
+    // auxiliary fields the interface kernels read on both sides: Phi, grad Phi, ref p, ref rho,
+    // Delta and the equilibrium state of the nodal refresh (temperature, q_liq, q_ice)
+    static constexpr int NFAUX = 10;
     __host__ __device__ static constexpr int face_aux(int i)
     {
-        return i < 4 ? OPHI + i : (i == 4 ? OREF : (i == 5 ? OREF + 1 : OTURB));
+        return i < 4 ? OPHI + i
+                     : (i == 4 ? OREF
+                               : (i == 5 ? OREF + 1
+                                         : (i == 6 ? OTURB : (i == 7 ? OMOIST : OMOIST + i - 6))));
     }
     __host__ __device__ static constexpr int hv_indexmap(int) { return 0; }
     __host__ __device__ static bool needs_gradflux(const Params &) { return true; }
@@ -202,6 +206,22 @@ struct MoistAtmos {
         }
         mixture(m, ts);
     }
+    // The thermodynamic state of (Q, aux) as the nodal refresh of this evaluation left it in
+    // aux.moisture (temperature, q_liq, q_ice).  The reference's recover_thermo_state repeats
+    // the saturation adjustment in every flux, wave-speed and gradient-argument evaluation
+    // (thermo_states.jl:40-60 in this snapshot); its result is a function of (Q, aux.Phi) alone,
+    // so the value the refresh stored for the same node in the same evaluation is that result,
+    // bit for bit -- on both sides of a face: the plus side is the neighbour's node, and a
+    // boundary state passes through update_aux (boundary_state below) before it is used.
+    __device__ static void thermo_state_refreshed(const Params &m, const double *Q,
+                                                  const double *aux, Thermo &ts)
+    {
+        ts.T = aux[OMOIST];
+        ts.q_tot = Q[5] / Q[0];
+        ts.q_liq = aux[OMOIST + 2];
+        ts.q_ice = aux[OMOIST + 3];
+        mixture(m, ts);
+    }
     __device__ static void mixture(const Params &m, Thermo &ts)
     {
         const double eps = m.R_v / m.R_d;
@@ -272,7 +292,7 @@ struct MoistAtmos {
                                             const double *aux, double, int)
     {
         Thermo ts;
-        thermo_state(m, Q, aux, ts);
+        thermo_state_refreshed(m, Q, aux, ts);
         flux_first_order_ts(m, F, Q, aux, ts);
     }
     // flux_first_order and wavespeed of one state from one thermodynamic state (the Rusanov flux
@@ -282,43 +302,7 @@ struct MoistAtmos {
                                           const double *Q, const double *aux, double, int)
     {
         Thermo ts;
-        thermo_state(m, Q, aux, ts);
-        flux_first_order_ts(m, F, Q, aux, ts);
-        wavespeed_ts(ws, n, Q, ts);
-    }
-    // per-node cache: temperature and condensate of the equilibrium state; the minus side of the
-    // faces reuses what the volume node computed (kernels.h node_cache_size)
-    static constexpr int NCACHE = 3;
-    __device__ static void node_cache(const Params &m, double *c, const double *Q, const double *aux)
-    {
-        Thermo ts;
-        thermo_state(m, Q, aux, ts);
-        c[0] = ts.T;
-        c[1] = ts.q_liq;
-        c[2] = ts.q_ice;
-    }
-    __device__ static void thermo_from_cache(const Params &m, const double *Q, const double *c,
-                                             Thermo &ts)
-    {
-        ts.T = c[0];
-        ts.q_tot = Q[5] / Q[0];
-        ts.q_liq = c[1];
-        ts.q_ice = c[2];
-        mixture(m, ts);
-    }
-    __device__ static void flux_first_order_cached(const Params &m, double *F, const double *Q,
-                                                   const double *aux, const double *c)
-    {
-        Thermo ts;
-        thermo_from_cache(m, Q, c, ts);
-        flux_first_order_ts(m, F, Q, aux, ts);
-    }
-    __device__ static void flux_wavespeed_cached(const Params &m, double *F, double *ws,
-                                                 const double *n, const double *Q,
-                                                 const double *aux, const double *c)
-    {
-        Thermo ts;
-        thermo_from_cache(m, Q, c, ts);
+        thermo_state_refreshed(m, Q, aux, ts);
         flux_first_order_ts(m, F, Q, aux, ts);
         wavespeed_ts(ws, n, Q, ts);
     }
@@ -526,7 +510,7 @@ struct MoistAtmos {
                                              const double *aux, double)
     {
         Thermo ts;
-        thermo_state(m, Q, aux, ts);
+        thermo_state_refreshed(m, Q, aux, ts);
         const double rhoinv = 1 / Q[0];
 #pragma unroll
         for (int d = 0; d < 3; ++d) G[d] = rhoinv * Q[1 + d];
@@ -566,7 +550,7 @@ struct MoistAtmos {
                                      const double *aux, double, int)
     {
         Thermo ts;
-        thermo_state(m, Q, aux, ts);
+        thermo_state_refreshed(m, Q, aux, ts);
         wavespeed_ts(ws, n, Q, ts);
     }
     __device__ static void wavespeed_ts(double *ws, const double *n, const double *Q,
