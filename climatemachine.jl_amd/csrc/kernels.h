@@ -1161,29 +1161,51 @@ __global__ void k_init_derived(typename P::Params prm, const double *aux, double
 
 // ---------------------------------------------------------------------------------
 // kernel_fillsendbuf! / kernel_transferrecvbuf!  MPIStateArrays.jl:837-871
-static __global__ void k_fillsendbuf(double *__restrict__ sendbuf, const double *__restrict__ buf,
-                              const int64_t *__restrict__ vmapsend, int64_t nvmap, int Np,
-                              int nvar)
+// The buffers are (nvar, nvmap) with the state index fastest (the reference's layout, what
+// travels); the arrays are (Np, nvar, nelem) with the node index fastest.  A block moves 64
+// consecutive map entries through LDS: the array side is touched with the node index fastest
+// across lanes (consecutive entries are neighbouring face nodes of one element), the buffer
+// side as one contiguous run of 64 * nvar doubles.
+constexpr int HALO_TILE = 64;
+static __global__ void __launch_bounds__(HALO_TILE) k_fillsendbuf(double *__restrict__ sendbuf,
+                                                                  const double *__restrict__ buf,
+                                                                  const int64_t *__restrict__ vmapsend,
+                                                                  int64_t nvmap, int Np, int nvar)
 {
-    const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (I >= nvmap * nvar) return;
-    const int64_t i = I / nvar;
-    const int s = (int)(I % nvar);
-    const int64_t id = vmapsend[i] - 1;
-    const int64_t e = id / Np, n = id % Np;
-    sendbuf[s + (int64_t)nvar * i] = buf[n + (int64_t)Np * (s + (int64_t)nvar * e)];
+    extern __shared__ double tile[];  // [HALO_TILE][nvar], state fastest
+    const int64_t i0 = (int64_t)blockIdx.x * HALO_TILE;
+    const int l = threadIdx.x;
+    const int64_t i = i0 + l;
+    if (i < nvmap) {
+        const int64_t id = vmapsend[i] - 1;
+        const int64_t e = id / Np, n = id % Np;
+        const double *src = buf + n + (int64_t)Np * nvar * e;
+        for (int s = 0; s < nvar; ++s) tile[l * nvar + s] = src[(int64_t)Np * s];
+    }
+    __syncthreads();
+    const int64_t cnt = (nvmap - i0 < HALO_TILE ? nvmap - i0 : HALO_TILE) * nvar;
+    double *dst = sendbuf + i0 * nvar;
+    for (int64_t q = l; q < cnt; q += HALO_TILE) dst[q] = tile[q];
 }
-static __global__ void k_transferrecvbuf(double *__restrict__ buf, const double *__restrict__ recvbuf,
-                                  const int64_t *__restrict__ vmaprecv, int64_t nvmap, int Np,
-                                  int nvar)
+static __global__ void __launch_bounds__(HALO_TILE) k_transferrecvbuf(double *__restrict__ buf,
+                                                                      const double *__restrict__ recvbuf,
+                                                                      const int64_t *__restrict__ vmaprecv,
+                                                                      int64_t nvmap, int Np, int nvar)
 {
-    const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (I >= nvmap * nvar) return;
-    const int64_t i = I / nvar;
-    const int s = (int)(I % nvar);
-    const int64_t id = vmaprecv[i] - 1;
-    const int64_t e = id / Np, n = id % Np;
-    buf[n + (int64_t)Np * (s + (int64_t)nvar * e)] = recvbuf[s + (int64_t)nvar * i];
+    extern __shared__ double tile[];
+    const int64_t i0 = (int64_t)blockIdx.x * HALO_TILE;
+    const int l = threadIdx.x;
+    const int64_t cnt = (nvmap - i0 < HALO_TILE ? nvmap - i0 : HALO_TILE) * nvar;
+    const double *src = recvbuf + i0 * nvar;
+    for (int64_t q = l; q < cnt; q += HALO_TILE) tile[q] = src[q];
+    __syncthreads();
+    const int64_t i = i0 + l;
+    if (i < nvmap) {
+        const int64_t id = vmaprecv[i] - 1;
+        const int64_t e = id / Np, n = id % Np;
+        double *dst = buf + n + (int64_t)Np * nvar * e;
+        for (int s = 0; s < nvar; ++s) dst[(int64_t)Np * s] = tile[l * nvar + s];
+    }
 }
 
 // ---------------------------------------------------------------------------------
