@@ -19,6 +19,9 @@ EveryDirection, HorizontalDirection, VerticalDirection = 0, 1, 2
 RusanovNumericalFlux, CentralNumericalFluxFirstOrder = 0, 1
 # methods of the dry AtmosModel (src/Atmos/Model/AtmosModel.jl:1006, :1154, :1515)
 RoeNumericalFlux, HLLCNumericalFlux, LMARSNumericalFlux = 2, 3, 4
+# RoeNumericalFluxMoist(; LM, HH, LV, LVPP) of the moist AtmosModel (AtmosModel.jl:1276-1513)
+(RoeNumericalFluxMoist, RoeNumericalFluxMoistLM, RoeNumericalFluxMoistHH, RoeNumericalFluxMoistLV,
+ RoeNumericalFluxMoistLVPP) = 5, 6, 7, 8, 9
 
 PHYSICS_ADVECTION_DIFFUSION = 1
 PHYSICS_DRY_ATMOS = 2
@@ -30,7 +33,8 @@ PHYSICS_MOIST_ATMOS = 6
 __all__ = [
     "EveryDirection", "HorizontalDirection", "VerticalDirection",
     "RusanovNumericalFlux", "CentralNumericalFluxFirstOrder", "RoeNumericalFlux",
-    "HLLCNumericalFlux", "LMARSNumericalFlux",
+    "HLLCNumericalFlux", "LMARSNumericalFlux", "RoeNumericalFluxMoist", "RoeNumericalFluxMoistLM",
+    "RoeNumericalFluxMoistHH", "RoeNumericalFluxMoistLV", "RoeNumericalFluxMoistLVPP",
     "InhomogeneousBC", "HomogeneousBC", "AdvectionDiffusion", "Pseudo1D",
     "ConstantHyperDiffusion", "DirectionSplitBox",
 ]

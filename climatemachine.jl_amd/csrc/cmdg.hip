@@ -1045,12 +1045,16 @@ int cmdg_create(const cmdg_desc *d, cmdg_handle *out)
         g_create_err = "only dim == 3 with one horizontal polynomial order is compiled in";
         return CMDG_ERR_UNSUPPORTED;
     }
-    if (d->nf_first < CMDG_RUSANOV || d->nf_first > CMDG_LMARS) {
+    if (d->nf_first < CMDG_RUSANOV || d->nf_first > CMDG_ROE_MOIST_LVPP) {
         g_create_err = "unknown first-order numerical flux";
         return CMDG_ERR_INVALID;
     }
-    if (d->nf_first >= CMDG_ROE && d->physics_id != CMDG_PHYSICS_DRY_ATMOS) {
+    if (d->nf_first >= CMDG_ROE && d->nf_first <= CMDG_LMARS && d->physics_id != CMDG_PHYSICS_DRY_ATMOS) {
         g_create_err = "Roe / HLLC / LMARS numerical fluxes are methods of the dry atmosphere law only";
+        return CMDG_ERR_UNSUPPORTED;
+    }
+    if (d->nf_first >= CMDG_ROE_MOIST && d->physics_id != CMDG_PHYSICS_MOIST_ATMOS) {
+        g_create_err = "RoeNumericalFluxMoist is a method of the moist atmosphere law (EquilMoist) only";
         return CMDG_ERR_UNSUPPORTED;
     }
     std::string err;

@@ -10,7 +10,13 @@ enum { XI1X1 = 0, XI2X1, XI3X1, XI1X2, XI2X2, XI3X2, XI1X3, XI2X3, XI3X3, VM, VM
 // sgeo row ids (Grids.jl:129-130)
 enum { SN1 = 0, SN2, SN3, SSM, SVMI };
 enum { DIR_EVERY = 0, DIR_HORIZONTAL = 1, DIR_VERTICAL = 2 };
-enum { NF_RUSANOV = 0, NF_CENTRAL = 1, NF_ROE = 2, NF_HLLC = 3, NF_LMARS = 4 };
+enum {
+    NF_RUSANOV = 0, NF_CENTRAL = 1, NF_ROE = 2, NF_HLLC = 3, NF_LMARS = 4,
+    // RoeNumericalFluxMoist(LM, HH, LV, LVPP) of the moist AtmosModel (AtmosModel.jl:1276-1513):
+    // plain, low-Mach, Harten-Hyman, LeVeque, positivity-preserving LeVeque
+    NF_ROE_MOIST = 5, NF_ROE_MOIST_LM = 6, NF_ROE_MOIST_HH = 7, NF_ROE_MOIST_LV = 8,
+    NF_ROE_MOIST_LVPP = 9
+};
 enum { BS_FIRST = 0, BS_GRADIENT = 1 };
 
 constexpr int NXCD = 8;

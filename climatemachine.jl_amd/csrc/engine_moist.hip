@@ -17,6 +17,13 @@ int counts_moist(const int32_t *ip, int32_t out[6])
 template <int NQ>
 static EngineBase *pick(const cmdg_desc *d, std::string &err)
 {
+    if (d->nf_first >= NF_ROE_MOIST) {  // the law's own RoeNumericalFluxMoist
+        if constexpr (NQ == 5) {
+            if (d->iparam[0] == 0) return make_engine<MoistAtmos<0, true>, NQ>(d);
+        }
+        err = "MoistAtmos: RoeNumericalFluxMoist is compiled for N = 4 with constant viscosity";
+        return nullptr;
+    }
     switch (d->iparam[0]) {
     case 0: return make_engine<MoistAtmos<0>, NQ>(d);
     case 1: return make_engine<MoistAtmos<1>, NQ>(d);

@@ -199,6 +199,21 @@ class MoistBubbleSetup:
         return rho, [rho * u, zero, zero], rhoe, rho * qt
 
 
+class IsentropicVortexMoistSetup:
+    """The isentropic vortex of test/Numerics/DGMethods/Euler/isentropicvortex.jl with
+    ``moisture = EquilMoist()`` (:335-339): the dry state plus ``rho q_tot = 0``."""
+
+    def __init__(self, ps):
+        from .atmos import IsentropicVortexSetup
+        self.dry = IsentropicVortexSetup(ps)
+        for k in ("domain_halflength", "translation_speed", "T_inf"):
+            setattr(self, k, getattr(self.dry, k))
+
+    def __call__(self, law, aux, coord, t):
+        rho, rhou, rhoe = self.dry(law, aux, coord, t)
+        return rho, rhou, rhoe, 0.0 * rho
+
+
 class MoistAtmosModel:
     physics_id = PHYSICS_MOIST_ATMOS
     off_phi, off_ref, off_turb, off_moist = 3, 7, 14, 15
@@ -207,8 +222,12 @@ class MoistAtmosModel:
     def __init__(self, init_state, ref_state, closure=CLOSURE_SMAGORINSKY, coefficient=None,
                  kinematic=True, subtract_off=True, sources=SRC_GRAVITY,
                  boundary_conditions=(BC_ATMOS_DEFAULT, BC_ATMOS_DEFAULT), param_set=None,
-                 maxiter=8, tolerance=1e-1):
+                 maxiter=8, tolerance=1e-1, no_orientation=False):
         self.ps = param_set or MoistParameters()
+        # NoOrientation + NoReferenceState (the moist isentropic vortex): the potential, its
+        # gradient, the reference state and Delta keep their slots of the auxiliary state and
+        # stay zero -- Phi = 0, nothing to subtract, no filter width
+        self.no_orientation = bool(no_orientation)
         self.init_state, self.ref_state = init_state, ref_state
         self.closure = int(closure)
         if coefficient is None:
@@ -221,8 +240,9 @@ class MoistAtmosModel:
         self.maxiter, self.tolerance = int(maxiter), float(tolerance)
         self.ngradflux = 3 + (10 if self.closure == CLOSURE_ANISO_MIN_DISS else 7) + 3
         # the dry model with the same options builds the shared part of the auxiliary state
-        self._dry = DryAtmosModel(None, orientation=ORIENT_FLAT, ref_state=ref_state,
-                                  smagorinsky=self.ps.C_smag, param_set=self.ps)
+        self._dry = None if self.no_orientation else DryAtmosModel(
+            None, orientation=ORIENT_FLAT, ref_state=ref_state, smagorinsky=self.ps.C_smag,
+            param_set=self.ps)
 
     def state_names(self):
         return ["ρ", "ρu[1]", "ρu[2]", "ρu[3]", "energy.ρe", "moisture.ρq_tot"]
@@ -251,8 +271,12 @@ class MoistAtmosModel:
         """coord, orientation, reference state (relative humidity 0: the moist entries stay 0)
         and Delta as for the dry model (atmos.py); the moisture block starts at 0 and is
         refreshed by the nodal update before it is read."""
-        d = self._dry.init_state_auxiliary(grid)               # (.., 3 + 4 + 7 + 1 + 2, ..)
         aux = np.zeros((grid.nelem, self.naux, grid.Np))
+        if self.no_orientation:
+            for d in range(3):
+                aux[:, d, :] = grid.vgeo[:, 12 + d, :]
+            return aux
+        d = self._dry.init_state_auxiliary(grid)               # (.., 3 + 4 + 7 + 1 + 2, ..)
         aux[:, :15, :] = d[:, :15, :]
         return aux
 

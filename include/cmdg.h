@@ -42,7 +42,11 @@ enum {
     CMDG_RUSANOV = 0, CMDG_CENTRAL_FIRST_ORDER = 1,
     /* methods the dry AtmosModel defines for itself (src/Atmos/Model/AtmosModel.jl:1006,
      * :1154, :1515); CMDG_PHYSICS_DRY_ATMOS without orientation / reference state only */
-    CMDG_ROE = 2, CMDG_HLLC = 3, CMDG_LMARS = 4
+    CMDG_ROE = 2, CMDG_HLLC = 3, CMDG_LMARS = 4,
+    /* RoeNumericalFluxMoist(; LM, HH, LV, LVPP) of the moist AtmosModel (AtmosModel.jl:1276-1513):
+     * CMDG_PHYSICS_MOIST_ATMOS with constant viscosity, N = 4 */
+    CMDG_ROE_MOIST = 5, CMDG_ROE_MOIST_LM = 6, CMDG_ROE_MOIST_HH = 7, CMDG_ROE_MOIST_LV = 8,
+    CMDG_ROE_MOIST_LVPP = 9
 };
 /* balance laws carried as device functors (pointwise Julia physics cannot cross a C ABI) */
 enum {

@@ -529,6 +529,135 @@ double orc_moist_saturation_adjustment(const orc_physics *ph, double e_int, doub
     return T;
 }
 
+/* numerical_flux_first_order!(::RoeNumericalFluxMoist, ::AtmosModel, ...)
+ * src/Atmos/Model/AtmosModel.jl:1276-1513; nf: 5 plain, 6 LM, 7 HH, 8 LV, 9 LVPP */
+static double roe_avg(double sM, double sP, double vM, double vP) { return (sM * vM + sP * vP) / (sM + sP); }
+static void solve6(double A[6][6], double *b)
+{ /* LU with partial pivoting */
+    for (int k = 0; k < 6; ++k) {
+        int piv = k;
+        double best = fabs(A[k][k]);
+        for (int i = k + 1; i < 6; ++i)
+            if (fabs(A[i][k]) > best) { best = fabs(A[i][k]); piv = i; }
+        if (piv != k) {
+            for (int j = 0; j < 6; ++j) { double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
+            double t = b[k]; b[k] = b[piv]; b[piv] = t;
+        }
+        const double inv = 1 / A[k][k];
+        for (int i = k + 1; i < 6; ++i) {
+            const double l = A[i][k] * inv;
+            A[i][k] = l;
+            for (int j = k + 1; j < 6; ++j) A[i][j] -= l * A[k][j];
+            b[i] -= l * b[k];
+        }
+    }
+    for (int i = 5; i >= 0; --i) {
+        double x = b[i];
+        for (int j = i + 1; j < 6; ++j) x -= A[i][j] * b[j];
+        b[i] = x / A[i][i];
+    }
+}
+static void mo_nf_law(const void *p_, int nf, double *fluxn, const double *n, const double *QM,
+                      const double *auxM, const double *QP, const double *auxP, double t, int facedir)
+{
+    const moist_t *m = (const moist_t *)p_;
+    double FM[18], FP[18];
+    for (int i = 0; i < 18; ++i) FM[i] = FP[i] = -0.0;
+    mo_flux1(p_, FM, QM, auxM, t, facedir);
+    mo_flux1(p_, FP, QP, auxP, t, facedir);
+    const double nh[3] = {n[0] / 2, n[1] / 2, n[2] / 2};
+    for (int s = 0; s < 6; ++s)
+        fluxn[s] += (FM[3 * s] + FP[3 * s]) * nh[0] + (FM[3 * s + 1] + FP[3 * s + 1]) * nh[1] +
+                    (FM[3 * s + 2] + FP[3 * s + 2]) * nh[2];
+    const double gam = m->cp_d / m->cv_d, eiv0 = e_int_v0(m), Phi = auxM[OPHI];
+    thermo_t tM, tP, ts;
+    thermo_state(m, QM, auxM, &tM);
+    thermo_state(m, QP, auxP, &tP);
+    const double rM = QM[0], rP = QP[0];
+    double uM[3], uP[3];
+    for (int d = 0; d < 3; ++d) { uM[d] = QM[1 + d] / rM; uP[d] = QP[1 + d] / rP; }
+    const double hM = QM[4] / rM + tM.R_m * tM.T, hP = QP[4] / rP + tP.R_m * tP.T;
+    const double qM = QM[5] / rM, qP = QP[5] / rP;
+    const double cM = soundspeed(&tM), cP = soundspeed(&tP);
+    const double sM = sqrt(rM), sP = sqrt(rP);
+    double ut[3];
+    for (int d = 0; d < 3; ++d) ut[d] = roe_avg(sM, sP, uM[d], uP[d]);
+    const double ht = roe_avg(sM, sP, hM, hP), qt = roe_avg(sM, sP, qM, qP);
+    const double rho = sqrt(rM * rP);
+    const double ei = roe_avg(sM, sP, tM.e_int, tP.e_int);
+    int unsat;
+    ts.q_tot = qt;
+    ts.T = saturation_adjustment(m, ei, rho, qt, &unsat);
+    if (unsat) ts.q_liq = ts.q_ice = 0.0;
+    else phase_partition_equil(m, ts.T, rho, qt, &ts.q_liq, &ts.q_ice);
+    ts.cv_m = cv_mix(m, ts.q_tot, ts.q_liq, ts.q_ice);
+    const double utut = ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2];
+    const double ct = sqrt((gam - 1) * (ht - utut / 2));
+    const double om = M_PI / 3, de = M_PI / 5;
+    const double rv[3] = {sin(om) * cos(de), cos(om) * cos(de), sin(de)};
+    const double t1[3] = {rv[1] * n[2] - rv[2] * n[1], rv[2] * n[0] - rv[0] * n[2], rv[0] * n[1] - rv[1] * n[0]};
+    const double t2[3] = {t1[1] * n[2] - t1[2] * n[1], t1[2] * n[0] - t1[0] * n[2], t1[0] * n[1] - t1[1] * n[0]};
+    const double unM = uM[0] * n[0] + uM[1] * n[1] + uM[2] * n[2];
+    const double unP = uP[0] * n[0] + uP[1] * n[1] + uP[2] * n[2];
+    const double un = ut[0] * n[0] + ut[1] * n[1] + ut[2] * n[2];
+    double ucm[3], ucp[3];
+    for (int d = 0; d < 3; ++d) { ucm[d] = ut[d] + ct * n[d]; ucp[d] = ut[d] - ct * n[d]; }
+    double cLM = ct;
+    if (nf == 6) {
+        const double MaP = sqrt(uP[0] * uP[0] + uP[1] * uP[1] + uP[2] * uP[2]) / cP;
+        const double MaM = sqrt(uM[0] * uM[0] + uM[1] * uM[1] + uM[2] * uM[2]) / cM;
+        const double Ma = (MaP + MaM) / 2, w = 1 - Ma * Ma;
+        cLM = ct * fmin(Ma * sqrt(4 + w * w) / (1 + Ma * Ma), 1.0);
+    }
+    double L[6] = {fabs(un - cLM), fabs(un), fabs(un), fabs(un), fabs(un + cLM), fabs(un)};
+    if (nf == 7) {
+        const double a = fmax(fabs(un), fmax(0.0, fmax(un - unM, unP - un)));
+        L[0] = fmax(fabs(un - cLM), fmax(0.0, fmax(un - cLM - (unM - cM), unP - cP - (un - cLM))));
+        L[1] = L[2] = L[3] = L[5] = a;
+        L[4] = fmax(fabs(un + cLM), fmax(0.0, fmax(un + cLM - (unM + cM), unP + cP - (un + cLM))));
+    }
+    if (nf == 8 || nf == 9) {
+        const int pp = nf == 9;
+        double dL1, dL2, dL3, dR1, dR2, dR3;
+        if (!pp) {
+            dL1 = fmax(0.0, un - unM); dL2 = fmax(0.0, un - cLM - (unM - cM)); dL3 = fmax(0.0, un + cLM - (unM + cM));
+            dR1 = fmax(0.0, unP - un); dR2 = fmax(0.0, unP - cP - (un - cLM)); dR3 = fmax(0.0, unP + cP - (un + cLM));
+        } else {
+            const double bL = fmin(un - cLM, unM - cM), bR = fmax(un + cLM, unP + cP);
+            const double bm = fmin(0.0, bL), bp = fmax(0.0, bR);
+            dL1 = fmax(0.0, un - bm); dL2 = fmax(0.0, un - cLM - bm); dL3 = fmax(0.0, un + cLM - bm);
+            dR1 = fmax(0.0, bp - un); dR2 = fmax(0.0, bp - (un - cLM)); dR3 = fmax(0.0, bp - (un + cLM));
+        }
+        double qa1, qa2, qa3;
+        if (un < dL1 && un > -dR1) qa1 = ((dL1 - dR1) * un + 2 * dL1 * dR1) / (dL1 + dR1);
+        else qa1 = fabs(un);
+        if ((pp ? un - cLM : un - ct) < dL2 && un - cLM > -dR2)
+            qa2 = ((dL2 - dR2) * (pp ? un - ct : un - cLM) + 2 * dL2 * dR2) / (dL2 + dR2);
+        else qa2 = fabs(un - cLM);
+        if (un + cLM < dL3 && (pp ? un + cLM : un + ct) > -dR3)
+            qa3 = ((dL3 - dR3) * (un + cLM) + 2 * dR3 * dR3) / (dL3 + dR3);
+        else qa3 = fabs(un + cLM);
+        L[0] = qa2; L[1] = L[2] = L[3] = L[5] = qa1; L[4] = qa3;
+    }
+    const double col[6][6] = {
+        {1, ucp[0], ucp[1], ucp[2], ht - ct * un, qt},
+        {0, t1[0], t1[1], t1[2], t1[0] * ut[0] + t1[1] * ut[1] + t1[2] * ut[2], 0},
+        {0, t2[0], t2[1], t2[2], t2[0] * ut[0] + t2[1] * ut[1] + t2[2] * ut[2], 0},
+        {1, ut[0], ut[1], ut[2], utut / 2 + Phi - m->T_0 * ts.cv_m, 0},
+        {1, ucm[0], ucm[1], ucm[2], ht + ct * un, qt},
+        {0, 0, 0, 0, eiv0, 1}};
+    double A[6][6], x[6] = {rP - rM, QP[1] - QM[1], QP[2] - QM[2], QP[3] - QM[3], QP[4] - QM[4], QP[5] - QM[5]};
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) A[i][j] = col[j][i];
+    solve6(A, x);
+    for (int j = 0; j < 6; ++j) x[j] *= L[j];
+    for (int i = 0; i < 6; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < 6; ++j) acc += col[j][i] * x[j];
+        fluxn[i] -= acc / 2;
+    }
+}
+
 orc_physics *orc_moist_new(const int *ip, const double *dp, int nf_first)
 {
     orc_physics *ph = (orc_physics *)calloc(1, sizeof(orc_physics));
@@ -568,5 +697,6 @@ orc_physics *orc_moist_new(const int *ip, const double *dp, int nf_first)
     ph->boundary_state_higher_order = mo_bhigher;
     ph->update_aux = mo_update_aux;
     ph->courant = mo_courant;
+    ph->numerical_flux_law = mo_nf_law;
     return ph;
 }

@@ -489,3 +489,26 @@ def simple_box_2dt_fields(Q3, A3, Q2, A2, grid2):
     for i, n in enumerate(O1.AUX_NAMES_2D):
         f[("baro aux", n)] = a0[:, i]
     return f
+
+
+def isentropic_vortex_moist_setup(level=1, N=4):
+    """test/Numerics/DGMethods/Euler/isentropicvortex.jl:308-370 with ``moisture = EquilMoist()``
+    (the RoeNumericalFluxMoist rows): dims = 3, NoReferenceState, NoOrientation,
+    ConstantDynamicViscosity(0), periodic BrickTopology, rho q_tot = 0."""
+    MO = cm.moist
+    ps = MO.MoistParameters()
+    setup = MO.IsentropicVortexMoistSetup(ps)
+    L = setup.domain_halflength
+    numelems = (2 ** (level - 1) * 5, 2 ** (level - 1) * 5, 1)
+    rng = [np.linspace(-L, L, n + 1) for n in numelems]
+    topl = M.BrickTopology(rng, periodicity=(True,) * 3, connectivity="face")
+    grid = M.DiscontinuousSpectralElementGrid(topl, N)
+    law = MO.MoistAtmosModel(setup, None, closure=MO.CLOSURE_CONSTANT, coefficient=0.0,
+                             kinematic=False, subtract_off=False, sources=0, boundary_conditions=(),
+                             param_set=ps, no_orientation=True)
+    timeend = 2 * L / 10 / setup.translation_speed
+    elementsize = min(2 * L / n for n in numelems)
+    cs = np.sqrt(ps.cp_d / ps.cv_d * ps.R_d * setup.T_inf)
+    dt = elementsize / cs / N ** 2
+    nsteps = int(np.ceil(timeend / dt))
+    return law, grid, timeend / nsteps, timeend, nsteps
