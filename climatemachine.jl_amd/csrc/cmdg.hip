@@ -302,10 +302,10 @@ int EngineBase::halo_pack(int s, double *array, int nvar)
         for (int r : nabrtorank) HIPCHK(hipStreamWaitEvent(s_comm, group[r]->slot[s].ev_pulled, 0));
     }
     if (nvmapsend > 0) {
+        const int64_t n = nvmapsend * nvar;
         prof_begin(CMDG_K_PACK, s_comm);
-        hipLaunchKernelGGL(k_fillsendbuf, dim3((unsigned)((nvmapsend + HALO_TILE - 1) / HALO_TILE)),
-                           dim3(HALO_TILE), sizeof(double) * HALO_TILE * nvar, s_comm, h.sendbuf, array,
-                           d_vmapsend, nvmapsend, Np, nvar);
+        hipLaunchKernelGGL(k_fillsendbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s_comm,
+                           h.sendbuf, array, d_vmapsend, nvmapsend, Np, nvar);
         prof_end(s_comm);
     }
     HIPCHK(hipEventRecord(h.ev_packed, s_comm));
@@ -378,10 +378,10 @@ int EngineBase::halo_end(int s, double *array, int nvar)
         HIPCHK(hipEventRecord(h.ev_pulled, s_comm));
     }
     if (nvmaprecv > 0) {
+        const int64_t n = nvmaprecv * nvar;
         prof_begin(CMDG_K_UNPACK, s_comm);
-        hipLaunchKernelGGL(k_transferrecvbuf, dim3((unsigned)((nvmaprecv + HALO_TILE - 1) / HALO_TILE)),
-                           dim3(HALO_TILE), sizeof(double) * HALO_TILE * nvar, s_comm, array, h.recvbuf,
-                           d_vmaprecv, nvmaprecv, Np, nvar);
+        hipLaunchKernelGGL(k_transferrecvbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           s_comm, array, h.recvbuf, d_vmaprecv, nvmaprecv, Np, nvar);
         prof_end(s_comm);
     }
     HIPCHK(hipEventRecord(h.ev_done, s_comm));
@@ -1191,9 +1191,9 @@ int cmdg_fillsendbuf(double *sendbuf, const double *buf, const int64_t *vmapsend
 {
     if (!sendbuf || !buf || !vmapsend || nvmap < 0 || Np < 1 || nstate < 1) return CMDG_ERR_INVALID;
     if (nvmap == 0) return CMDG_OK;
-    if (nstate > 96) return CMDG_ERR_INVALID;  // one LDS tile of 64 entries (48 KB)
-    hipLaunchKernelGGL(k_fillsendbuf, dim3((unsigned)((nvmap + HALO_TILE - 1) / HALO_TILE)), dim3(HALO_TILE),
-                       sizeof(double) * HALO_TILE * nstate, 0, sendbuf, buf, vmapsend, nvmap, Np, nstate);
+    const int64_t n = nvmap * nstate;
+    hipLaunchKernelGGL(k_fillsendbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, sendbuf, buf,
+                       vmapsend, nvmap, Np, nstate);
     return hipGetLastError() == hipSuccess && hipStreamSynchronize(0) == hipSuccess ? CMDG_OK : CMDG_ERR_HIP;
 }
 
@@ -1202,9 +1202,9 @@ int cmdg_transferrecvbuf(double *buf, const double *recvbuf, const int64_t *vmap
 {
     if (!buf || !recvbuf || !vmaprecv || nvmap < 0 || Np < 1 || nstate < 1) return CMDG_ERR_INVALID;
     if (nvmap == 0) return CMDG_OK;
-    if (nstate > 96) return CMDG_ERR_INVALID;
-    hipLaunchKernelGGL(k_transferrecvbuf, dim3((unsigned)((nvmap + HALO_TILE - 1) / HALO_TILE)), dim3(HALO_TILE),
-                       sizeof(double) * HALO_TILE * nstate, 0, buf, recvbuf, vmaprecv, nvmap, Np, nstate);
+    const int64_t n = nvmap * nstate;
+    hipLaunchKernelGGL(k_transferrecvbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, buf,
+                       recvbuf, vmaprecv, nvmap, Np, nstate);
     return hipGetLastError() == hipSuccess && hipStreamSynchronize(0) == hipSuccess ? CMDG_OK : CMDG_ERR_HIP;
 }
 

@@ -287,11 +287,14 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
     constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGF = P::NGF,
                   NHYP = P::NHYP, NHG = 3 * P::NGL, NFA = P::NFAUX,
                   NSURF = SurfDims<NQ, NQV>::NSURF, NGFS = USE_GF ? NGF : 0,
-                  NCA = node_cache_size<P>::value, NMF = NS + NFA + NGFS + NHYP + NCA;
+                  NCA = node_cache_size<P>::value, NMF = NFA + NGFS + NHYP + NCA;
     __shared__ double sD[NQ * NQ + (NQV == NQ ? 0 : NQV * NQV)];
     const double *const sDv = sD + (NQV == NQ ? 0 : NQ * NQ);  // vertical derivative matrix
     __shared__ double sF[3 * NS * Np];  // contravariant flux [d][s][ijk]; later the accumulator
-    __shared__ double sM[NMF * NSURF];  // minus-side state of the surface nodes [field][sidx]
+    __shared__ double sM[(NMF > 0 ? NMF : 1) * NSURF];  // minus side, surface nodes [field][sidx]
+    // the prognostic state of every node: minus side of the faces, and the "Q" of the fused
+    // update at the end (re-reading it from memory 20 us after the first read misses L2)
+    __shared__ double sQ[NS * Np];
     double *const sT = sF;              // tendency accumulator [s][ijk] (aliases sF after phase 2)
     const int tid = threadIdx.x;
     const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
@@ -332,17 +335,17 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
         for (int s = 0; s < NHYP; ++s)
             lhyp[s] = a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)];
         const int sidx = surf_index<NQ, NQV>(tid);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sQ[s * Np + tid] = lQ[s];
         if (sidx >= 0) {  // stage the minus side of the interface phase
 #pragma unroll
-            for (int s = 0; s < NS; ++s) sM[s * NSURF + sidx] = lQ[s];
-#pragma unroll
-            for (int s = 0; s < NFA; ++s) sM[(NS + s) * NSURF + sidx] = laux[P::face_aux(s)];
+            for (int s = 0; s < NFA; ++s) sM[s * NSURF + sidx] = laux[P::face_aux(s)];
             if (use_gf) {
 #pragma unroll
-                for (int s = 0; s < NGF; ++s) sM[(NS + NFA + s) * NSURF + sidx] = lgf[s];
+                for (int s = 0; s < NGF; ++s) sM[(NFA + s) * NSURF + sidx] = lgf[s];
             }
 #pragma unroll
-            for (int s = 0; s < NHYP; ++s) sM[(NS + NFA + NGFS + s) * NSURF + sidx] = lhyp[s];
+            for (int s = 0; s < NHYP; ++s) sM[(NFA + NGFS + s) * NSURF + sidx] = lhyp[s];
         }
         Vec<3 * NS> F, F2;
         F.negzero();
@@ -353,7 +356,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
             if (sidx >= 0) {
 #pragma unroll
                 for (int s = 0; s < NCA; ++s)
-                    sM[(NS + NFA + NGFS + NHYP + s) * NSURF + sidx] = lc[s];
+                    sM[(NFA + NGFS + NHYP + s) * NSURF + sidx] = lc[s];
             }
         } else {
             P::flux_first_order(a.prm, F, lQ, laux, a.t, a.model_dir);
@@ -459,21 +462,21 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
 #pragma unroll
             for (int s = 0; s < NAUX; ++s) auxM[s] = 0;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) QM[s] = sM[s * NSURF + sidx];
+            for (int s = 0; s < NS; ++s) QM[s] = sQ[s * Np + fp.vidM];
             Vec<NCA> cM;  // the law's per-node cache of the minus side (see node_cache_size)
 #pragma unroll
-            for (int s = 0; s < NCA; ++s) cM[s] = sM[(NS + NFA + NGFS + NHYP + s) * NSURF + sidx];
+            for (int s = 0; s < NCA; ++s) cM[s] = sM[(NFA + NGFS + NHYP + s) * NSURF + sidx];
 #pragma unroll
-            for (int s = 0; s < NFA; ++s) auxM[P::face_aux(s)] = sM[(NS + s) * NSURF + sidx];
+            for (int s = 0; s < NFA; ++s) auxM[P::face_aux(s)] = sM[s * NSURF + sidx];
 #pragma unroll
             for (int s = 0; s < NGF; ++s) gfM[s] = gfP[s] = 0.0;
             if (use_gf) {
 #pragma unroll
-                for (int s = 0; s < NGF; ++s) gfM[s] = sM[(NS + NFA + s) * NSURF + sidx];
+                for (int s = 0; s < NGF; ++s) gfM[s] = sM[(NFA + s) * NSURF + sidx];
                 load_state<NGF, Np>(gfP, a.gf, fp.vidP, fp.eP);
             }
 #pragma unroll
-            for (int s = 0; s < NHYP; ++s) hypM[s] = sM[(NS + NFA + NGFS + s) * NSURF + sidx];
+            for (int s = 0; s < NHYP; ++s) hypM[s] = sM[(NFA + NGFS + s) * NSURF + sidx];
             load_state<NS, Np>(QPn, a.Q, fp.vidP, fp.eP);
 #pragma unroll
             for (int s = 0; s < NAUX; ++s) auxPn[s] = 0;
@@ -557,9 +560,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
             const int64_t o = tid + (int64_t)Np * (s + (int64_t)NS * e);
             const double T = sT[s * Np + tid];
             if constexpr (LSRK) {  // update!: Q += rkb*dt*dQ; dQ *= rka
-                // re-read (an L1/L2 hit) rather than ten more live registers: keeping the state
-                // costs a wave per SIMD (profiles/r02_ab_mfma_contraction.txt, "keepq")
-                a.Qout[o] = a.Q[o] + a.rkb_dt * T;
+                a.Qout[o] = sQ[s * Np + tid] + a.rkb_dt * T;
                 a.tendency[o] = T * a.rka_next;
             } else {
                 a.tendency[o] = T;
@@ -1161,51 +1162,29 @@ __global__ void k_init_derived(typename P::Params prm, const double *aux, double
 
 // ---------------------------------------------------------------------------------
 // kernel_fillsendbuf! / kernel_transferrecvbuf!  MPIStateArrays.jl:837-871
-// The buffers are (nvar, nvmap) with the state index fastest (the reference's layout, what
-// travels); the arrays are (Np, nvar, nelem) with the node index fastest.  A block moves 64
-// consecutive map entries through LDS: the array side is touched with the node index fastest
-// across lanes (consecutive entries are neighbouring face nodes of one element), the buffer
-// side as one contiguous run of 64 * nvar doubles.
-constexpr int HALO_TILE = 64;
-static __global__ void __launch_bounds__(HALO_TILE) k_fillsendbuf(double *__restrict__ sendbuf,
-                                                                  const double *__restrict__ buf,
-                                                                  const int64_t *__restrict__ vmapsend,
-                                                                  int64_t nvmap, int Np, int nvar)
+static __global__ void k_fillsendbuf(double *__restrict__ sendbuf, const double *__restrict__ buf,
+                              const int64_t *__restrict__ vmapsend, int64_t nvmap, int Np,
+                              int nvar)
 {
-    extern __shared__ double tile[];  // [HALO_TILE][nvar], state fastest
-    const int64_t i0 = (int64_t)blockIdx.x * HALO_TILE;
-    const int l = threadIdx.x;
-    const int64_t i = i0 + l;
-    if (i < nvmap) {
-        const int64_t id = vmapsend[i] - 1;
-        const int64_t e = id / Np, n = id % Np;
-        const double *src = buf + n + (int64_t)Np * nvar * e;
-        for (int s = 0; s < nvar; ++s) tile[l * nvar + s] = src[(int64_t)Np * s];
-    }
-    __syncthreads();
-    const int64_t cnt = (nvmap - i0 < HALO_TILE ? nvmap - i0 : HALO_TILE) * nvar;
-    double *dst = sendbuf + i0 * nvar;
-    for (int64_t q = l; q < cnt; q += HALO_TILE) dst[q] = tile[q];
+    const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= nvmap * nvar) return;
+    const int64_t i = I / nvar;
+    const int s = (int)(I % nvar);
+    const int64_t id = vmapsend[i] - 1;
+    const int64_t e = id / Np, n = id % Np;
+    sendbuf[s + (int64_t)nvar * i] = buf[n + (int64_t)Np * (s + (int64_t)nvar * e)];
 }
-static __global__ void __launch_bounds__(HALO_TILE) k_transferrecvbuf(double *__restrict__ buf,
-                                                                      const double *__restrict__ recvbuf,
-                                                                      const int64_t *__restrict__ vmaprecv,
-                                                                      int64_t nvmap, int Np, int nvar)
+static __global__ void k_transferrecvbuf(double *__restrict__ buf, const double *__restrict__ recvbuf,
+                                  const int64_t *__restrict__ vmaprecv, int64_t nvmap, int Np,
+                                  int nvar)
 {
-    extern __shared__ double tile[];
-    const int64_t i0 = (int64_t)blockIdx.x * HALO_TILE;
-    const int l = threadIdx.x;
-    const int64_t cnt = (nvmap - i0 < HALO_TILE ? nvmap - i0 : HALO_TILE) * nvar;
-    const double *src = recvbuf + i0 * nvar;
-    for (int64_t q = l; q < cnt; q += HALO_TILE) tile[q] = src[q];
-    __syncthreads();
-    const int64_t i = i0 + l;
-    if (i < nvmap) {
-        const int64_t id = vmaprecv[i] - 1;
-        const int64_t e = id / Np, n = id % Np;
-        double *dst = buf + n + (int64_t)Np * nvar * e;
-        for (int s = 0; s < nvar; ++s) dst[(int64_t)Np * s] = tile[l * nvar + s];
-    }
+    const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= nvmap * nvar) return;
+    const int64_t i = I / nvar;
+    const int s = (int)(I % nvar);
+    const int64_t id = vmaprecv[i] - 1;
+    const int64_t e = id / Np, n = id % Np;
+    buf[n + (int64_t)Np * (s + (int64_t)nvar * e)] = recvbuf[s + (int64_t)nvar * i];
 }
 
 // ---------------------------------------------------------------------------------
