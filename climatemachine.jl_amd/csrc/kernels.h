@@ -788,19 +788,27 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? C
 #pragma unroll
             for (int s = 0; s < NGRAD; ++s)
                 GM[s] = (GMASK >> s & 1) ? sG[s * Np + fp.vidM] : 0.0;  // == G(Q-, aux-)
-            load_state<NS, Np>(QP, a.Q, fp.vidP, fp.eP);
-            load_state<NAUX, Np>(auxP, a.aux, fp.vidP, fp.eP);
             GP.negzero();
-            P::gradient_argument(a.prm, GP, QP, auxP, a.t);
             Vec<NGF> lgf;
             lgf.negzero();
             Vec<3 * NGRAD> tg, nGM;
             if (fp.bctag == 0) {  // CentralNumericalFluxGradient  NumericalFluxes.jl:67-83
+                // the plus side is read inside the branch that uses it: of the neighbour's
+                // auxiliary columns only those the law's gradient argument touches are gathered
+                load_state<NS, Np>(QP, a.Q, fp.vidP, fp.eP);
+                load_state<NAUX, Np>(auxP, a.aux, fp.vidP, fp.eP);
+                P::gradient_argument(a.prm, GP, QP, auxP, a.t);
 #pragma unroll
                 for (int s = 0; s < NGRAD; ++s)
 #pragma unroll
                     for (int d = 0; d < 3; ++d) tg[d + 3 * s] = fp.n[d] * (GP[s] + GM[s]) / 2;
             } else {  // numerical_boundary_flux_gradient!  NumericalFluxes.jl:85-123
+                // e+ = e-, vid+ = vid- on boundary faces (:686-692): the plus side starts as
+                // a copy of the minus side, already loaded
+#pragma unroll
+                for (int s = 0; s < NS; ++s) QP[s] = QM[s];
+#pragma unroll
+                for (int s = 0; s < NAUX; ++s) auxP[s] = auxM[s];
                 Vec<NS> Q1;
                 Vec<NAUX> aux1;
                 for (int s = 0; s < NS; ++s) Q1[s] = 0;

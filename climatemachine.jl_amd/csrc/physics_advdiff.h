@@ -45,9 +45,10 @@ struct AdvDiff {
     static constexpr bool HAS_SOURCE = false;
     static constexpr int NDER = 0;
     __host__ __device__ static bool needs_gradflux(const Params &) { return DIFF; }
-    // auxiliary fields the interface kernels need from the minus side (all of them)
-    static constexpr int NFAUX = NAUX;
-    __host__ __device__ static constexpr int face_aux(int i) { return i; }
+    // auxiliary fields the interior-face fluxes read on either side: the velocity (first-order
+    // flux and wave speed); boundary faces load the whole minus-side auxiliary state themselves
+    static constexpr int NFAUX = ADV ? 3 : 0;
+    __host__ __device__ static constexpr int face_aux(int i) { return OU + i; }
     __host__ __device__ static constexpr int hv_indexmap(int) { return 0; }
 
     static constexpr int BC_INHOM(int o) { return 1 << o; }
