@@ -117,13 +117,15 @@ def build_workload(cm, name, rank, size, ne, args, nhorz=None, nvert=None):
                np.linspace(0.0, 3000.0, nz + 1)]
         topl = M.StackedBrickTopology(rng, periodicity=(True, True, False),
                                       boundary=((0, 0), (0, 0), (1, 2)), rank=rank, size=size)
-        grid = M.DiscontinuousSpectralElementGrid(topl, 6)
+        grid = M.DiscontinuousSpectralElementGrid(topl, getattr(args, "bomex_order", 6))
         law = MO.bomex_model(3000.0)
         desc = {"workload": "BOMEX moist LES (BASELINE configs[3]), stacked brick %dx%dx%d elements, "
-                            "N=6, EquilMoist (saturation adjustment in every flux evaluation, as "
+                            "N=%d, EquilMoist (saturation adjustment in every flux evaluation, as "
                             "in the reference snapshot), SmagorinskyLilly, BOMEX sources and "
-                            "surface fluxes, LSRK54 explicit, Rusanov, fp64" % (nx, ny, nz),
-                "elements": nx * ny * nz, "nodes_per_element": 343, "states": law.ns,
+                            "surface fluxes, LSRK54 explicit, Rusanov, fp64"
+                            % (nx, ny, nz, getattr(args, "bomex_order", 6)),
+                "elements": nx * ny * nz,
+                "nodes_per_element": (getattr(args, "bomex_order", 6) + 1) ** 3, "states": law.ns,
                 "parallelism": "element partition (Hilbert, whole columns), %d rank(s)" % size}
         return law, grid, (0, 0), 0.004, desc
     raise SystemExit("unknown workload %s" % name)
@@ -275,6 +277,8 @@ def main():
     ap.add_argument("--ne", type=int, default=32, help="advdiff-brick: elements per side per rank")
     ap.add_argument("--bomex-ne", type=int, default=16,
                     help="bomex: ne x ne x 2 ne elements per rank (32: the 65 536 elements of configs[3])")
+    ap.add_argument("--bomex-order", type=int, default=6,
+                    help="bomex: polynomial order (6: configs[3]; 4 for kernel-shape comparisons)")
     ap.add_argument("--nhorz", type=int, default=0, help="heldsuarez: elements per cube edge")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "weak-small"],
                     help="heldsuarez: weak = 43 200 elements per GPU (n_horz 30/42/60/85 at "
