@@ -12,7 +12,7 @@ for set in "$@"; do
   rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_$i -o p --output-format csv -- python3 $root/bench.py $args --no-cpu --no-events > /tmp/pmc_$i.log 2>&1 || { tail -5 /tmp/pmc_$i.log; exit 1; }
 done
 python3 - "$root/$out" "$i" <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
 out, n = sys.argv[1], int(sys.argv[2])
 res = collections.defaultdict(dict)
 for i in range(1, n + 1):
@@ -21,7 +21,9 @@ for i in range(1, n + 1):
     cnt = collections.defaultdict(set)
     for f in files:
         for r in csv.DictReader(open(f)):
-            k = r['Kernel_Name'].split('<')[0].split('(')[0].replace('void cmdg::', '')
+            k = r['Kernel_Name'].replace('void cmdg::', '')
+            # PMC_FULLNAME=1 keeps the template arguments (one entry per instantiation)
+            k = k.split('(')[0][:110] if os.environ.get('PMC_FULLNAME') else k.split('<')[0].split('(')[0]
             acc[k][r['Counter_Name']] += float(r['Counter_Value'])
             cnt[k].add(r['Dispatch_Id'])
     for k in acc:

@@ -512,3 +512,69 @@ def isentropic_vortex_moist_setup(level=1, N=4):
     dt = elementsize / cs / N ** 2
     nsteps = int(np.ceil(timeend / dt))
     return law, grid, timeend / nsteps, timeend, nsteps
+
+
+# ---- the reference's dim = 2 problems on the 3-D kernels -----------------------------------
+# A 2-D grid (xi1 horizontal, xi2 vertical) is the y-invariant slice of a 3-D one: one periodic
+# element across y, fields constant in y, 2-D vectors (a, b) embedded as (a, 0, b).  The xi2
+# derivative and the y-face terms then vanish (to rounding), what remains is the 2-D operator,
+# and mass-weighted norms carry the factor sqrt(Ly).
+DIM2_N = {0: np.array([1.0, 0.0, 1.0]) / np.sqrt(2), 1: np.array([1.0, 0.0, 0.0]),
+          2: np.array([0.0, 0.0, 1.0])}
+
+
+def pseudo1d_dim2_setup(Ne=4, N=4, direction=0, flux_bc=False):
+    """pseudo1D_advection_diffusion.jl:293-368 with dim = 2 (n = (1,1)/sqrt 2, (1,0), (0,1))."""
+    x = np.linspace(-1, 1, Ne + 1)
+    Ly = 2.0 / Ne
+    topl = M.StackedBrickTopology([x, np.array([0.0, Ly]), x],
+                                  boundary=((1, 2), (0, 0), (1, 2)),
+                                  periodicity=(False, True, False), connectivity="full")
+    grid = M.DiscontinuousSpectralElementGrid(topl, N)
+    law = BL.AdvectionDiffusion(3, BL.Pseudo1D(DIM2_N[direction], 1.0, 1 / 100, -1 / 2, 1 / 10),
+                                (BL.InhomogeneousBC(0), BL.InhomogeneousBC(1)), flux_bc=flux_bc)
+    dt = (1.0 / 4) / (Ne * N ** 2)
+    dt = 1.0 / np.ceil(1.0 / dt)
+    return law, grid, dt, np.sqrt(Ly)
+
+
+class _HyperDiffusionDim2(BL.ConstantHyperDiffusion):
+    """ConstantHyperDiffusion{2, dir} (periodic_3D_hyperdiffusion.jl:40-63): k = (1, 2) and
+    D[1:2, 1:2], embedded as k = (1, 0, 2) and the (x, z) block of a 3 x 3 tensor."""
+
+    def __init__(self, direction, D):
+        D = np.asarray(D, dtype=np.float64)
+        D3 = np.zeros((3, 3))
+        for a, i in enumerate((0, 2)):
+            for b, j in enumerate((0, 2)):
+                D3[i, j] = D[a, b]
+        super().__init__(3, direction, D3)
+        self.D2 = D[:2, :2].copy()
+
+    def _c(self):
+        k = np.array([1.0, 2.0])
+        kD = (k[:, None] * k[None, :]) * self.D2
+        if self.direction == BL.EveryDirection:
+            return (k[0] * k[0] + k[1] * k[1]) * (kD[0, 0] + kD[1, 0] + kD[0, 1] + kD[1, 1])
+        if self.direction == BL.HorizontalDirection:
+            return k[0] * k[0] * kD[0, 0]
+        return k[1] ** 2 * kD[1, 1]
+
+    def initial_condition(self, coord, t):
+        return np.sin(1.0 * coord[0] + 2.0 * coord[2]) * np.exp(-self._c() * t)
+
+
+def periodic_hyperdiffusion_dim2_setup(Ne=4, N=4, direction=0):
+    """periodic_3D_hyperdiffusion.jl:107-322 with dim = 2."""
+    D = np.array([[9, 3, 5], [3, 7, 4], [5, 4, 10]], dtype=np.float64) / 50 / 100
+    x = np.linspace(0.0, 2 * np.pi, Ne + 1)
+    Ly = 2 * np.pi / Ne
+    topl = M.StackedBrickTopology([x, np.array([0.0, Ly]), x], periodicity=(True,) * 3,
+                                  connectivity="full")
+    grid = M.DiscontinuousSpectralElementGrid(topl, N)
+    law = BL.AdvectionDiffusion(3, _HyperDiffusionDim2(direction, D), (),
+                                advection=False, diffusion=False, hyperdiffusion=True)
+    dx = M.grids.min_node_distance(grid)
+    dt = dx ** 4 / 25 / D.sum()
+    dt = 1.0 / np.ceil(1.0 / dt)
+    return law, grid, dt, np.sqrt(Ly)
