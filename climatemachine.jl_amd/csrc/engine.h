@@ -264,7 +264,8 @@ struct EngineT : EngineBase {
 #else
         const bool gfl = P::needs_gradflux(prm);
 #endif
-        const dim3 grid((unsigned)n), block(KDims<NQ_, NQV_>::NT);
+        using SH = TendencyShape<P, NQ_, NQV_>;
+        const dim3 grid((unsigned)SH::blocks(n)), block(SH::NT);
         const PassArgs<P> args = make_args(c, elems, n, direction);
         if (c.lsrk) {
             if (gfl)

@@ -21,10 +21,17 @@
 #ifndef CMDG_TEND_MINW
 #define CMDG_TEND_MINW 1
 #endif
+// elements per work-group of k_tendency for N >= 5 (see TendencyShape)
+#ifndef CMDG_TEND_EPB_LARGE
+#define CMDG_TEND_EPB_LARGE 2
+#endif
 // k_gradients: the Held-Suarez instantiation needs 130 VGPRs unconstrained (3 waves/SIMD);
 // asking for 4 gives 128 without scratch and 9 % less time per launch (profiles/r01_ab_*.txt)
 #ifndef CMDG_GRAD_MINW
 #define CMDG_GRAD_MINW 4
+#endif
+#ifndef CMDG_GRAD_BOUND_LARGE
+#define CMDG_GRAD_BOUND_LARGE 1024
 #endif
 #ifndef CMDG_LAP_MINW
 #define CMDG_LAP_MINW 1
@@ -278,29 +285,59 @@ struct SurfDims {
 };
 
 // ---------------------------------------------------------------------------------
+// Launch shape of the tendency pass.  N <= 4: one element per work-group, 192 threads.  Larger
+// elements: 343 nodes are six waves, which the four SIMDs of a CU take as 2-1-2-1 -- two of them
+// carry twice the work and a second six-wave work-group does not become resident above 128
+// VGPRs (profiles/r02_lds_occupancy.jsonl).  Two elements per work-group (686 threads, eleven
+// waves, 3-3-3-2) even that out; the minus side of the faces is then read from memory instead
+// of being staged, so that both elements' flux buffers fit the LDS of a CU.
+template <class P, int NQ, int NQV>
+struct TendencyShape {
+    using KD = KDims<NQ, NQV>;
+    static constexpr int EPB = (KD::Np > 125 && node_cache_size<P>::value == 0) ? CMDG_TEND_EPB_LARGE : 1;
+    static constexpr int NTE = EPB == 1 ? KD::NT : (KD::Np > KD::NFT ? KD::Np : KD::NFT);
+    static constexpr int NT = EPB == 1 ? KD::NT : ((EPB * NTE + 63) / 64) * 64;
+    static int64_t blocks(int64_t nelems) { return (nelems + EPB - 1) / EPB; }
+};
+
+// ---------------------------------------------------------------------------------
 // Tendency pass: volume_tendency! (:64-548) + dgsem_interface_tendency! (:588-901),
 // optionally fused with the LSRK update! (LowStorageRungeKuttaMethod.jl:146-158).
 template <class P, int NQ, int NQV, bool LSRK, bool USE_GF>
-__global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tendency(const PassArgs<P> a)
+__global__ void __launch_bounds__((TendencyShape<P, NQ, NQV>::NT), CMDG_TEND_MINW) k_tendency(const PassArgs<P> a)
 {
     using KD = KDims<NQ, NQV>;
+    using SH = TendencyShape<P, NQ, NQV>;
+    constexpr int EPB = SH::EPB;
+    constexpr bool STAGE_M = EPB == 1;
     constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGF = P::NGF,
                   NHYP = P::NHYP, NHG = 3 * P::NGL, NFA = P::NFAUX,
                   NSURF = SurfDims<NQ, NQV>::NSURF, NGFS = USE_GF ? NGF : 0,
-                  NCA = node_cache_size<P>::value, NMF = NFA + NGFS + NHYP + NCA;
+                  NCA = node_cache_size<P>::value,
+                  NMF = (STAGE_M ? NFA + NGFS + NHYP : 0) + NCA, OCA = NMF - NCA;
     __shared__ double sD[NQ * NQ + (NQV == NQ ? 0 : NQV * NQV)];
     const double *const sDv = sD + (NQV == NQ ? 0 : NQ * NQ);  // vertical derivative matrix
-    __shared__ double sF[3 * NS * Np];  // contravariant flux [d][s][ijk]; later the accumulator
-    __shared__ double sM[(NMF > 0 ? NMF : 1) * NSURF];  // minus side, surface nodes [field][sidx]
+    // contravariant flux [d][s][ijk]; later the accumulator
+    __shared__ double sF_[EPB * 3 * NS * Np];
+    // minus side, surface nodes [field][sidx]
+    __shared__ double sM_[EPB * (NMF > 0 ? NMF : 1) * (NMF > 0 ? NSURF : 1)];
     // the prognostic state of every node: minus side of the faces, and the "Q" of the fused
     // update at the end (re-reading it from memory 20 us after the first read misses L2)
-    __shared__ double sQ[NS * Np];
+    __shared__ double sQ_[EPB * NS * Np];
+    // this thread's element of the work-group and its index there
+    const int sub = EPB == 1 ? 0 : (int)threadIdx.x / SH::NTE;
+    const int tid = EPB == 1 ? (int)threadIdx.x : (int)threadIdx.x - sub * SH::NTE;
+    const int64_t li = (int64_t)EPB * xcd_remap(blockIdx.x, gridDim.x) + sub;
+    const bool live = EPB == 1 || (sub < EPB && li < a.nelems);
+    const int64_t e = live ? a.elems[li] - 1 : 0;
+    const int lsub = live ? sub : 0;
+    double *const sF = sF_ + lsub * (3 * NS * Np);
+    double *const sM = sM_ + lsub * ((NMF > 0 ? NMF : 1) * (NMF > 0 ? NSURF : 1));
+    double *const sQ = sQ_ + lsub * (NS * Np);
     double *const sT = sF;              // tendency accumulator [s][ijk] (aliases sF after phase 2)
-    const int tid = threadIdx.x;
-    const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
-    if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
+    if (threadIdx.x < NQ * NQ) sD[threadIdx.x] = a.g.D[threadIdx.x];
     if constexpr (NQV != NQ) {
-        if (tid < NQV * NQV) sD[NQ * NQ + tid] = a.g.Dv[tid];
+        if (threadIdx.x < NQV * NQV) sD[NQ * NQ + threadIdx.x] = a.g.Dv[threadIdx.x];
     }
     const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
     // USE_GF: does flux_second_order depend on the gradient-flux state at all?  With zero
@@ -313,12 +350,12 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
     {
         int f_f = 0, f_n = 0;
         KD::face_task(tid, f_f, f_n);
-        face_on = tid < KD::NFT && (f_f < 4 ? hz : vt);
+        face_on = live && tid < KD::NFT && (f_f < 4 ? hz : vt);
         if (face_on) face_index<NQ, NQV>(a.g, e, tid, f_f, f_idP, f_bctag);
     }
     Vec<NS> S;
     double MI = 0;
-    if (tid < Np) {
+    if (live && tid < Np) {
         const double *vg = a.g.vgeo + (int64_t)Np * a.g.nvgeo * e + tid;
         const double M = vg[VM * Np];
         MI = vg[VMI * Np];
@@ -337,7 +374,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
         const int sidx = surf_index<NQ, NQV>(tid);
 #pragma unroll
         for (int s = 0; s < NS; ++s) sQ[s * Np + tid] = lQ[s];
-        if (sidx >= 0) {  // stage the minus side of the interface phase
+        if (STAGE_M && sidx >= 0) {  // stage the minus side of the interface phase
 #pragma unroll
             for (int s = 0; s < NFA; ++s) sM[s * NSURF + sidx] = laux[P::face_aux(s)];
             if (use_gf) {
@@ -356,7 +393,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
             if (sidx >= 0) {
 #pragma unroll
                 for (int s = 0; s < NCA; ++s)
-                    sM[(NFA + NGFS + NHYP + s) * NSURF + sidx] = lc[s];
+                    sM[(OCA + s) * NSURF + sidx] = lc[s];
             }
         } else {
             P::flux_first_order(a.prm, F, lQ, laux, a.t, a.model_dir);
@@ -394,7 +431,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
     }
     __syncthreads();
     Vec<NS> Tv;
-    if (tid < Np) {
+    if (live && tid < Np) {
         const int i = tid % NQ, j = (tid / NQ) % NQ, k = tid / (NQ * NQ);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -436,7 +473,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
         }
     }
     __syncthreads();  // every read of sF is done: it becomes the accumulator sT
-    if (tid < Np) {
+    if (live && tid < Np) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) sT[s * Np + tid] = Tv[s];
     }
@@ -465,18 +502,27 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
             for (int s = 0; s < NS; ++s) QM[s] = sQ[s * Np + fp.vidM];
             Vec<NCA> cM;  // the law's per-node cache of the minus side (see node_cache_size)
 #pragma unroll
-            for (int s = 0; s < NCA; ++s) cM[s] = sM[(NFA + NGFS + NHYP + s) * NSURF + sidx];
+            for (int s = 0; s < NCA; ++s) cM[s] = sM[(OCA + s) * NSURF + sidx];
 #pragma unroll
-            for (int s = 0; s < NFA; ++s) auxM[P::face_aux(s)] = sM[s * NSURF + sidx];
+            for (int s = 0; s < NFA; ++s)
+                auxM[P::face_aux(s)] =
+                    STAGE_M ? sM[s * NSURF + sidx]
+                            : a.aux[fp.vidM + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * e)];
 #pragma unroll
             for (int s = 0; s < NGF; ++s) gfM[s] = gfP[s] = 0.0;
             if (use_gf) {
+                if constexpr (STAGE_M) {
 #pragma unroll
-                for (int s = 0; s < NGF; ++s) gfM[s] = sM[(NFA + s) * NSURF + sidx];
+                    for (int s = 0; s < NGF; ++s) gfM[s] = sM[(NFA + s) * NSURF + sidx];
+                } else {
+                    load_state<NGF, Np>(gfM, a.gf, fp.vidM, e);
+                }
                 load_state<NGF, Np>(gfP, a.gf, fp.vidP, fp.eP);
             }
 #pragma unroll
-            for (int s = 0; s < NHYP; ++s) hypM[s] = sM[(NFA + NGFS + s) * NSURF + sidx];
+            for (int s = 0; s < NHYP; ++s)
+                hypM[s] = STAGE_M ? sM[(NFA + NGFS + s) * NSURF + sidx]
+                                  : a.hypgrad[fp.vidM + (int64_t)Np * (s + (int64_t)NHG * e)];
             load_state<NS, Np>(QPn, a.Q, fp.vidP, fp.eP);
 #pragma unroll
             for (int s = 0; s < NAUX; ++s) auxPn[s] = 0;
@@ -554,7 +600,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_TEND_MINW) k_tenden
         }
         __syncthreads();
     }
-    if (tid < Np) {
+    if (live && tid < Np) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int64_t o = tid + (int64_t)Np * (s + (int64_t)NS * e);
@@ -636,7 +682,10 @@ __host__ __device__ constexpr unsigned gradient_argument_mask()
 }
 
 template <class P, int NQ, int NQV = NQ, bool USE_GF = true>
-__global__ void __launch_bounds__((KDims<NQ, NQV>::NT), (NQ == 5 && NQV == 5 ? CMDG_GRAD_MINW : 1)) k_gradients(const PassArgs<P> a)
+// (six-wave work-groups of the large elements share a CU only at <= 128 VGPRs, see TendencyShape;
+// a launch bound of 1024 threads is the hard form of that request)
+__global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LARGE : KDims<NQ, NQV>::NT),
+                                   (NQ == 5 && NQV == 5 ? CMDG_GRAD_MINW : 1)) k_gradients(const PassArgs<P> a)
 {
     using KD = KDims<NQ, NQV>;
     constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGRAD = P::NGRAD,
