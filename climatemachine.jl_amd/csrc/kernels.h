@@ -1,4 +1,5 @@
-// Hand-written gfx950 kernels of the DG hot path.  One workgroup per element:
+// Hand-written gfx950 kernels of the DG hot path.  One workgroup per element (the tendency pass
+// of elements above N = 4 takes two, see TendencyShape):
 //   phase 1  thread = volume node: pointwise physics, contravariant fluxes / gradient
 //            arguments staged in LDS;
 //   phase 2  thread = volume node: (N+1)-point contractions with D out of LDS, result
