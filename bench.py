@@ -407,8 +407,8 @@ def main():
         traffic, traffic_src = None, None
         pmc_files = {("heldsuarez", 43200): "r02_heldsuarez_n30_pmc_hbm_per_launch.json",
                      ("heldsuarez", 5808): "r01_heldsuarez_n11_pmc_hbm_per_launch.json",
-                     ("risingbubble", 8000): "r01_risingbubble_8000_pmc_hbm_per_launch.json",
-                     ("bomex", 8192): "r01_bomex_n6_8192_pmc_hbm_per_launch.json"}
+                     ("risingbubble", 8000): "r02_risingbubble_8000_pmc_hbm_per_launch.json",
+                     ("bomex", 8192): "r02_bomex_n6_8192_pmc_hbm_per_launch.json"}
         pmc_name = pmc_files.get((args.workload, grid.nreal))
         if pmc_name and world == 1 and not args.filter:
             pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
