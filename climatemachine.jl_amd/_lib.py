@@ -12,6 +12,7 @@ CMDG_K = dict(GRADIENTS=0, DIVGRAD=1, GRADLAP=2, TENDENCY=3, PACK=4, UNPACK=5, U
               FILTER=7, STACK_INTEGRAL=8, TRANSPORT=9, HALO_EXPOSED=10)
 STACK_MAXOUT = 8
 OPT_KEEP_GRADFLUX = 1
+OPT_STACK_HEIGHT = 2
 
 
 class CmdgStackIntegralDesc(C.Structure):

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <tuple>
 
 #include "engine.h"
 #include "filters.h"
@@ -86,6 +87,8 @@ EngineBase::~EngineBase()
     if (W[0]) hipFree(W[0]);
     if (W[1]) hipFree(W[1]);
     if (d_D) hipFree(d_D);
+    if (d_interior_tiled) hipFree(d_interior_tiled);
+    if (d_exterior_tiled) hipFree(d_exterior_tiled);
     if (d_faceP) hipFree(d_faceP);
     if (d_faceG) hipFree(d_faceG);
     if (derived) hipFree(derived);
@@ -132,9 +135,9 @@ int EngineBase::init(const cmdg_desc *d)
     g.vmapP = d->vmapP;
     g.elemtobndy = d->elemtobndy;
     g.nvgeo = d->nvgeo;
-    d_interior = d->interiorelems;
+    d_interior = d_interior_user = d->interiorelems;
     ninterior = d->ninterior;
-    d_exterior = d->exteriorelems;
+    d_exterior = d_exterior_user = d->exteriorelems;
     nexterior = d->nexterior;
     d_activedofs = d->activedofs;
     d_vmapsend = d->vmapsend;
@@ -343,6 +346,40 @@ int EngineBase::halo_post(const int *slots, int nslots)
     }
     // only now: a failure above leaves the slots free for the next call
     for (int q = 0; q < nslots; ++q) slot[slots[q]].active = true;
+    return CMDG_OK;
+}
+
+// Launch order of the element lists (results do not depend on it).  Column by column, a tall
+// stack fills an XCD's work-group slots by itself and the expensive horizontal face gathers find
+// nothing of their neighbours in its L2; tiles of TILE_C columns x TILE_L levels put horizontal
+// neighbours (consecutive columns of the Hilbert order) in flight together:
+// profiles/r02_ab_launch_tiles.txt (BOMEX, 32 levels: -8 % on k_tendency; rising bubble, 20: -3 %;
+// ocean box, 16, and Held-Suarez, 8: nothing to gain).
+int EngineBase::set_stack_height(int nv)
+{
+    constexpr int TILE_C = 32, TILE_L = 4, MIN_HEIGHT = 17;
+    if (nv < 0 || (nv > 0 && (!stacked || nreal % nv != 0)))
+        return fail(CMDG_ERR_INVALID, "stack height: not a stacked topology or nreal is not a multiple of it");
+    HIPCHK(hipStreamSynchronize(s_comp));
+    d_interior = d_interior_user;
+    d_exterior = d_exterior_user;
+    if (nv < MIN_HEIGHT) return CMDG_OK;
+    for (int which = 0; which < 2; ++which) {
+        const int64_t n = which ? nexterior : ninterior;
+        if (n == 0) continue;
+        std::vector<int64_t> h((size_t)n);
+        HIPCHK(hipMemcpy(h.data(), which ? d_exterior_user : d_interior_user, sizeof(int64_t) * n,
+                         hipMemcpyDeviceToHost));
+        auto key = [&](int64_t e1) {
+            const int64_t e = e1 - 1, col = e / nv, lev = e % nv;
+            return std::make_tuple(col / TILE_C, lev / TILE_L, col % TILE_C, lev % TILE_L);
+        };
+        std::stable_sort(h.begin(), h.end(), [&](int64_t x, int64_t y) { return key(x) < key(y); });
+        int64_t *&own = which ? d_exterior_tiled : d_interior_tiled;
+        if (!own) HIPCHK(hipMalloc(&own, sizeof(int64_t) * n));
+        HIPCHK(hipMemcpy(own, h.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice));
+        (which ? d_exterior : d_interior) = own;
+    }
     return CMDG_OK;
 }
 
@@ -1169,6 +1206,7 @@ int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value)
     EngineBase *e = h->eng;
     switch (option) {
     case CMDG_OPT_KEEP_GRADFLUX: e->keep_gradflux = value != 0; return CMDG_OK;
+    case CMDG_OPT_STACK_HEIGHT: return set_err(h, e->set_stack_height(value));
     default: return set_err(h, e->fail(CMDG_ERR_INVALID, "cmdg_set_option: unknown option"));
     }
 }

@@ -59,6 +59,10 @@ struct EngineBase {
     int nf_first = 0, direction = 0, diffusion_direction = 0, stacked = 0;
     GridDev g{};
     const int64_t *d_interior = nullptr, *d_exterior = nullptr;
+    // CMDG_OPT_STACK_HEIGHT: the caller's lists and the engine's own tiled copies of them
+    const int64_t *d_interior_user = nullptr, *d_exterior_user = nullptr;
+    int64_t *d_interior_tiled = nullptr, *d_exterior_tiled = nullptr;
+    int set_stack_height(int nv);
     int64_t ninterior = 0, nexterior = 0;
     const uint8_t *d_activedofs = nullptr;
     double *d_D = nullptr;

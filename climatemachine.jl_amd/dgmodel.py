@@ -121,10 +121,14 @@ class DGModel:
         self._desc = d
         if keep_gradient_flux:
             self.set_option(_lib.OPT_KEEP_GRADFLUX, 1)
+        if g.topology.isstacked and g.topology.stacksize:
+            # length(topology.stacksize): lets the engine pick the launch order of tall stacks
+            self.set_option(_lib.OPT_STACK_HEIGHT, int(g.topology.stacksize))
 
     def set_option(self, option, value):
         """``cmdg_set_option``: ``_lib.OPT_KEEP_GRADFLUX`` = refresh ``state_gradient_flux`` in
-        every evaluation even when the law's fluxes never read it (zero viscosity)."""
+        every evaluation even when the law's fluxes never read it (zero viscosity);
+        ``_lib.OPT_STACK_HEIGHT`` = elements per vertical stack (launch order only)."""
         _lib.check(self.L.cmdg_set_option(self.handle, int(option), int(value)), self.handle)
 
     def close(self):

@@ -153,8 +153,13 @@ int cmdg_synchronize(cmdg_handle h);
  *   nine columns of dg.state_gradient_flux neither formed, stored nor exchanged -- the tendency
  *   is bit-identical without them.  1 restores the reference's behaviour of refreshing
  *   state_gradient_flux in every evaluation (DGModel.jl:126-206), for callers that read it
- *   (diagnostics, the diffusive Courant number). */
-enum { CMDG_OPT_KEEP_GRADFLUX = 1 };
+ *   (diagnostics, the diffusive Courant number).
+ * CMDG_OPT_STACK_HEIGHT (default 0 = unknown): number of elements of a vertical stack of a stacked
+ *   topology (length(topology.stacksize); elements of a stack are contiguous, e = ev + (eh - 1) nv).
+ *   Results do not depend on it.  With tall stacks (more than 16 elements) the engine walks its
+ *   element lists in tiles of 32 columns x 4 levels instead of column by column, so that the
+ *   elements in flight on one XCD are horizontal neighbours whose face gathers meet in its L2. */
+enum { CMDG_OPT_KEEP_GRADFLUX = 1, CMDG_OPT_STACK_HEIGHT = 2 };
 int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value);
 
 /* ---- halo (MPIStateArrays.jl:411-514, 837-871) -------------------------------- */

@@ -532,3 +532,31 @@ def test_heat_equation_gpu(cm, torch, direction, level):
     assert abs(err - exp) <= g["rtol"] * exp or err < exp, (err, exp)     # the test's criterion
     assert abs(err - exp) <= 1e-6 * exp
     dg.close()
+
+
+def test_stack_height_option_changes_launch_order_only(cm, torch):
+    """CMDG_OPT_STACK_HEIGHT: with tall stacks (> 16 elements) the element lists are walked in
+    tiles of columns x levels; tendencies are bit-identical to the column-by-column order, and
+    a height that does not divide the element count is refused."""
+    M, BL = cm.mesh, cm.balancelaws
+    rng = [np.linspace(-1, 1, 4), np.linspace(-1, 1, 3), np.linspace(-1, 1, 19)]
+    topl = M.StackedBrickTopology(rng, boundary=((1, 2),) * 3, periodicity=(False,) * 3)
+    grid = M.DiscontinuousSpectralElementGrid(topl, 4)
+    n = np.ones(3) / np.sqrt(3)
+    law = BL.AdvectionDiffusion(3, BL.Pseudo1D(n, 1.0, 1 / 100, -1 / 2, 1 / 10),
+                                (BL.InhomogeneousBC(0), BL.InhomogeneousBC(1)))
+    dg = cm.dgmodel.DGModel(law, grid)          # sets the option from topology.stacksize (18)
+    assert grid.topology.stacksize == 18
+    Q = dg.init_ode_state(0.0)
+    Q += 1e-3 * torch.randn_like(Q)
+    T_tiled = dg.create_state()
+    dg(T_tiled, Q, 0.1, 1.0, 0.0)
+    dg.set_option(cm._lib.OPT_STACK_HEIGHT, 0)  # back to the caller's order
+    T_cols = dg.create_state()
+    dg(T_cols, Q, 0.1, 1.0, 0.0)
+    torch.cuda.synchronize()
+    assert torch.equal(T_tiled, T_cols)
+    assert float(T_cols.abs().max()) > 0
+    with pytest.raises(Exception):
+        dg.set_option(cm._lib.OPT_STACK_HEIGHT, 7)
+    dg.close()
