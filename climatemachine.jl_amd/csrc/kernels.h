@@ -285,6 +285,15 @@ struct SurfDims {
         NQ * NQ * NQV - (NQ - 2) * (NQ - 2) * (NQV > 2 ? NQV - 2 : 0);
 };
 
+// A law may ask for its own register budget in the gradient pass (waves per SIMD the allocator
+// is to aim for): light laws gain residency, heavy ones keep the default.
+template <class P, class = void>
+struct grad_min_waves : std::integral_constant<int, CMDG_GRAD_MINW> {
+};
+template <class P>
+struct grad_min_waves<P, std::void_t<decltype(P::GRAD_MIN_WAVES)>> : std::integral_constant<int, P::GRAD_MIN_WAVES> {
+};
+
 // ---------------------------------------------------------------------------------
 // Launch shape of the tendency pass.  N <= 4: one element per work-group, 192 threads.  Larger
 // elements: 343 nodes are six waves, which the four SIMDs of a CU take as 2-1-2-1 -- two of them
@@ -686,7 +695,7 @@ template <class P, int NQ, int NQV = NQ, bool USE_GF = true>
 // (six-wave work-groups of the large elements share a CU only at <= 128 VGPRs, see TendencyShape;
 // a launch bound of 1024 threads is the hard form of that request)
 __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LARGE : KDims<NQ, NQV>::NT),
-                                   (NQ == 5 && NQV == 5 ? CMDG_GRAD_MINW : 1)) k_gradients(const PassArgs<P> a)
+                                   (NQ == 5 && NQV == 5 ? grad_min_waves<P>::value : 1)) k_gradients(const PassArgs<P> a)
 {
     using KD = KDims<NQ, NQV>;
     constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGRAD = P::NGRAD,

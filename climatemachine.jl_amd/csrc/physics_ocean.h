@@ -41,6 +41,7 @@ struct HydroBoussinesq {
     // the face fluxes read w and pkin (and y never): aux columns 1, 2
     static constexpr int NFAUX = 2;
     __host__ __device__ static constexpr int face_aux(int i) { return 1 + i; }
+    static constexpr int GRAD_MIN_WAVES = 6;  // k_gradients: 98 VGPRs unconstrained
 
     static void make_params(Params &p, const int32_t *ip, const double *dp)
     {
