@@ -75,22 +75,32 @@ struct AdvDiff {
             const double a = xn - mu - al * t;
             return exp(-(a * a) / (4 * be * (de + t))) / sqrt(1 + t / de);
         } else if (m.problem == 1) {  // ConstantHyperDiffusion (:44-63)
+            // (every loop has constant bounds: an index that is only known at run time would send
+            // the node's coordinates and the parameter block through scratch memory)
             const int dim = (int)m.d[9], dir = (int)m.d[10];
             const double k[3] = {1, 2, 3};
             double c;
             if (dir == 0 || dir == 1) {
                 const int dd = dir == 0 ? dim : dim - 1;
                 double s2 = 0, skd = 0;
-                for (int i = 0; i < dd; ++i) s2 += k[i] * k[i];
-                for (int j = 0; j < dd; ++j)
-                    for (int i = 0; i < dd; ++i) skd += k[i] * k[j] * m.d[i + 3 * j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if (i < dd) s2 += k[i] * k[i];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (i < dd && j < dd) skd += k[i] * k[j] * m.d[i + 3 * j];
                 c = s2 * skd;
             } else {
-                c = k[dim - 1] * k[dim - 1] *
-                    (k[dim - 1] * k[dim - 1] * m.d[(dim - 1) + 3 * (dim - 1)]);
+                const double kd = dim == 1 ? 1.0 : (dim == 2 ? 2.0 : 3.0);
+                const double Dd = dim == 1 ? m.d[0] : (dim == 2 ? m.d[4] : m.d[8]);
+                c = kd * kd * (kd * kd * Dd);
             }
             double kx = 0;
-            for (int i = 0; i < dim; ++i) kx += k[i] * x[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < dim) kx += k[i] * x[i];
             return sin(kx) * exp(-c * t);
         } else if (m.problem == 2) {  // d[0] = mu, d[1..3] = k
             const double *k = m.d + 1;
