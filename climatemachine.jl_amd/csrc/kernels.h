@@ -285,6 +285,26 @@ struct SurfDims {
         NQ * NQ * NQV - (NQ - 2) * (NQ - 2) * (NQV > 2 ? NQV - 2 : 0);
 };
 
+// compute_gradient_flux! of a node whose gradient ARGUMENT is at hand (the volume node's own, the
+// minus side of a face): a law whose gradient flux needs a quantity that is also an entry of its
+// argument (the dry atmosphere's theta_v under SmagorinskyLilly, a pow) takes it from there.
+template <class P, class = void>
+struct has_gradient_flux_g : std::false_type {
+};
+template <class P>
+struct has_gradient_flux_g<P, std::void_t<decltype(&P::gradient_flux_g)>> : std::true_type {
+};
+template <class P>
+__device__ __forceinline__ void law_gradient_flux(const typename P::Params &prm, double *gf,
+                                                  const double *g, const double *Q, const double *aux,
+                                                  double t, const double *G)
+{
+    if constexpr (has_gradient_flux_g<P>::value)
+        P::gradient_flux_g(prm, gf, g, Q, aux, t, G);
+    else
+        P::gradient_flux(prm, gf, g, Q, aux, t);
+}
+
 // A law may ask for its own register budget in the gradient pass (waves per SIMD the allocator
 // is to aim for): light laws gain residency, heavy ones keep the default.
 template <class P, class = void>
@@ -822,8 +842,11 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LA
             Vec<NGF> o1, o2;
             o1.negzero();
             o2.negzero();
-            if (hz) P::gradient_flux(a.prm, o1, gh, lQ, laux, a.t);
-            if (vt) P::gradient_flux(a.prm, o2, gv, lQ, laux, a.t);
+            Vec<NGRAD> Gn;  // this node's gradient argument (every entry is staged when NGF > 0)
+#pragma unroll
+            for (int s = 0; s < NGRAD; ++s) Gn[s] = (GMASK >> s & 1) ? sG[s * Np + tid] : 0.0;
+            if (hz) law_gradient_flux<P>(a.prm, o1, gh, lQ, laux, a.t, Gn);
+            if (vt) law_gradient_flux<P>(a.prm, o2, gv, lQ, laux, a.t, Gn);
 #pragma unroll
             for (int s = 0; s < NGF; ++s)
                 sA[s * Np + tid] = hz ? (vt ? o1[s] + o2[s] : o1[s]) : o2[s];
@@ -884,7 +907,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LA
 #pragma unroll
                     for (int d = 0; d < 3; ++d) tg[d + 3 * s] = fp.n[d] * GP[s];
             }
-            if constexpr (NGF > 0) P::gradient_flux(a.prm, lgf, tg, QM, auxM, a.t);
+            if constexpr (NGF > 0) law_gradient_flux<P>(a.prm, lgf, tg, QM, auxM, a.t, GM);
 #pragma unroll
             for (int s = 0; s < NGRAD; ++s)
 #pragma unroll
@@ -899,7 +922,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LA
             if constexpr (NGF > 0) {
                 Vec<NGF> visc;
                 for (int s = 0; s < NGF; ++s) visc[s] = 0;
-                P::gradient_flux(a.prm, visc, nGM, QM, auxM, a.t);
+                law_gradient_flux<P>(a.prm, visc, nGM, QM, auxM, a.t, GM);
 #pragma unroll
                 for (int s = 0; s < NGF; ++s) corr[s] = fp.vMI * fp.sM * (lgf[s] - visc[s]);
             }

@@ -478,10 +478,24 @@ struct DryAtmos {
         return m.R_d / m.R_d * (T / exner);
     }
     __device__ static void gradient_flux(const Params &m, double *gf, const double *g,
-                                         const double *Q, const double *aux, double)
+                                         const double *Q, const double *aux, double t)
+    {
+        double th = 0;
+        if constexpr (SMAG) th = theta_v(m, air_T(m, internal_energy(m, Q, aux)), Q[0]);
+        gradient_flux_th(m, gf, g, aux, th);
+    }
+    // the same with the node's gradient argument at hand: G[4] is theta_v of this (Q, aux), the
+    // very expression above (gradient_argument), so the pow is not evaluated again
+    __device__ static void gradient_flux_g(const Params &m, double *gf, const double *g,
+                                           const double *, const double *aux, double,
+                                           const double *G)
+    {
+        gradient_flux_th(m, gf, g, aux, SMAG ? G[SMAG ? 4 : 0] : 0.0);
+    }
+    __device__ static void gradient_flux_th(const Params &, double *gf, const double *g,
+                                            const double *aux, double th)
     {
         if constexpr (SMAG) {  // N^2 = dot(grad theta_v, grad Phi) / theta_v  (:451-466)
-            const double th = theta_v(m, air_T(m, internal_energy(m, Q, aux)), Q[0]);
             gf[9] = (g[0 + 3 * 4] * aux[OPHI + 1] + g[1 + 3 * 4] * aux[OPHI + 2] +
                      g[2 + 3 * 4] * aux[OPHI + 3]) / th;
         }
