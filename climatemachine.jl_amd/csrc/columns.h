@@ -36,12 +36,13 @@ __global__ __launch_bounds__(256) void k_stack_integral(StackArgs a)
     const int sl = tid / Nij, ij = tid % Nij;
     const int64_t eh = a.h0 + (int64_t)blockIdx.x * SPB + sl;
     if (sl >= SPB || eh >= a.h0 + a.nhorz) return;
-    double lint[NOUT][NQ], lker[NOUT][NQ];
+    double lint[NOUT][NQ], lker[NOUT][NQ], lnext[NOUT][NQ];
 #pragma unroll
     for (int s = 0; s < NOUT; ++s)
 #pragma unroll
         for (int k = 0; k < NQ; ++k) lint[s][k] = 0;
-    for (int ev = 0; ev < a.nvert; ++ev) {
+    // integrand of one element of the stack (integral_load_auxiliary_state! times the Jacobian)
+    auto load_kernel = [&](int ev, double (&out)[NOUT][NQ]) {
         const int64_t e = ev + eh * a.nvert;
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
@@ -52,9 +53,18 @@ __global__ __launch_bounds__(256) void k_stack_integral(StackArgs a)
                 const double f = a.is_state[s]
                                      ? a.Q[ijk + (int64_t)Np * (a.src[s] + (int64_t)a.nstate * e)]
                                      : a.aux[ijk + (int64_t)Np * (a.src[s] + (int64_t)a.naux * e)];
-                lker[s][k] = (a.scale[s] * f) * Jc;
+                out[s][k] = (a.scale[s] * f) * Jc;
             }
         }
+    };
+    load_kernel(0, lker);
+    for (int ev = 0; ev < a.nvert; ++ev) {
+        const int64_t e = ev + eh * a.nvert;
+        // the next element's integrand is requested before this element's results are stored:
+        // source and destination may be the same column of the same array, which keeps the
+        // compiler from moving these loads above the stores by itself, and the walk up the
+        // stack would pay a full memory latency per element
+        if (ev + 1 < a.nvert) load_kernel(ev + 1, lnext);
 #pragma unroll
         for (int s = 0; s < NOUT; ++s)
 #pragma unroll
@@ -70,6 +80,10 @@ __global__ __launch_bounds__(256) void k_stack_integral(StackArgs a)
                 lint[s][k] = lint[s][NQ - 1];
             }
         }
+#pragma unroll
+        for (int s = 0; s < NOUT; ++s)
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) lker[s][k] = lnext[s][k];
     }
 }
 
@@ -90,17 +104,33 @@ __global__ __launch_bounds__(256) void k_reverse_stack_integral(StackArgs a)
         for (int s = 0; s < NOUT; ++s)
             lT[s] = a.aux[ijk + (int64_t)Np * (a.src[s] + (int64_t)a.naux * et)];
     }
+    // every element's values are read before anything is stored, and the next element's before
+    // this element's stores (source and destination are columns of one array: the compiler may
+    // not reorder them, and a load-store pair per value would serialise 5 x NOUT x nvert latencies)
+    double v[NOUT][NQ], vnext[NOUT][NQ];
+    auto load_values = [&](int ev, double (&out)[NOUT][NQ]) {
+        const int64_t e = ev + eh * a.nvert;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+#pragma unroll
+            for (int s = 0; s < NOUT; ++s)
+                out[s][k] = a.aux[ij + Nij * k + (int64_t)Np * (a.src[s] + (int64_t)a.naux * e)];
+    };
+    load_values(0, v);
     for (int ev = 0; ev < a.nvert; ++ev) {
         const int64_t e = ev + eh * a.nvert;
+        if (ev + 1 < a.nvert) load_values(ev + 1, vnext);
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
             const int ijk = ij + Nij * k;
 #pragma unroll
-            for (int s = 0; s < NOUT; ++s) {
-                const double v = a.aux[ijk + (int64_t)Np * (a.src[s] + (int64_t)a.naux * e)];
-                a.aux[ijk + (int64_t)Np * (a.dst[s] + (int64_t)a.naux * e)] = lT[s] - v;
-            }
+            for (int s = 0; s < NOUT; ++s)
+                a.aux[ijk + (int64_t)Np * (a.dst[s] + (int64_t)a.naux * e)] = lT[s] - v[s][k];
         }
+#pragma unroll
+        for (int s = 0; s < NOUT; ++s)
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) v[s][k] = vnext[s][k];
     }
 }
 
