@@ -393,6 +393,20 @@ def main():
         if not kern:
             print(json.dumps({"ms_per_step": 1e3 * el / args.steps, "value": dofs / el}), flush=True)
             return
+        # partitioned runs: rank 0's ghost exchange as the event pass saw it -- the RCCL group of
+        # each exchange on the halo stream, and the time the compute stream had nothing left to
+        # do but wait for it (zero when the exchange finished behind the interior kernels)
+        halo = None
+        if world > 1 or os.environ.get("BENCH_HALO_BLOCK"):
+            halo = {"rank": 0, "real_elements": int(grid.nreal),
+                    "ghost_elements": int(grid.nelem - grid.nreal),
+                    "neighbours": [int(r) for r in grid.nabrtorank]}
+            for key, name in (("TRANSPORT", "rccl_group"), ("HALO_EXPOSED", "exposed")):
+                ms, n = dg.profile_get(key)
+                if n:
+                    halo[name + "_avg_us"] = 1e3 * ms / n
+                    halo[name + "_ms_per_step"] = ms / args.steps
+                    halo["exchanges_per_step"] = n / args.steps
         dom = max((k for k in kern if k in ("GRADIENTS", "DIVGRAD", "GRADLAP", "TENDENCY")),
                   key=lambda k: kern[k][0] * kern[k][1])
         avg_ms, nl = kern[dom]
@@ -427,6 +441,7 @@ def main():
             "node_updates_per_s": dofs / el / law.ns,
             "state_finite": finite,
             "kernels_ms": {k: {"avg_ms": v[0], "launches": v[1]} for k, v in kern.items()},
+            "halo": halo,
             "roofline": {"bound": "hbm", "kernel": "k_%s" % dom.lower(), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
