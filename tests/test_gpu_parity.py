@@ -560,3 +560,44 @@ def test_stack_height_option_changes_launch_order_only(cm, torch):
     with pytest.raises(Exception):
         dg.set_option(cm._lib.OPT_STACK_HEIGHT, 7)
     dg.close()
+
+
+def test_tiled_launch_order_on_a_partition(cm, torch):
+    """Tall stacks (18 elements) cut over two ranks of one process: the tiled interior and
+    exterior lists of each rank reproduce the single-rank tendency element by element."""
+    M, BL = cm.mesh, cm.balancelaws
+    rng = [np.linspace(-1, 1, 5), np.linspace(-1, 1, 4), np.linspace(-1, 1, 19)]
+    n = np.ones(3) / np.sqrt(3)
+
+    def make(rank, size):
+        topl = M.StackedBrickTopology(rng, boundary=((1, 2),) * 3, periodicity=(False,) * 3,
+                                      rank=rank, size=size)
+        grid = M.DiscontinuousSpectralElementGrid(topl, 4)
+        law = BL.AdvectionDiffusion(3, BL.Pseudo1D(n, 1.0, 1 / 100, -1 / 2, 1 / 10),
+                                    (BL.InhomogeneousBC(0), BL.InhomogeneousBC(1)))
+        return law, grid, cm.dgmodel.DGModel(law, grid)
+
+    law, grid, dg1 = make(0, 1)
+    Q1 = dg1.init_ode_state(0.0)
+    T1 = dg1.create_state()
+    dg1(T1, Q1, 0.1, 1.0, 0.0)
+    torch.cuda.synchronize()
+    ref = {int(g): T1[i].cpu().numpy() for i, g in enumerate(grid.topology.globalelems[:grid.nreal])}
+    parts = [make(r, 2) for r in range(2)]
+    dgs = [p[2] for p in parts]
+    Qs, Ts = [], []
+    for _, g, d in parts:
+        assert g.topology.stacksize == 18
+        q = d.init_ode_state(0.0)
+        q[g.nreal:] = float("nan")
+        Qs.append(q)
+        Ts.append(d.create_state())
+    torch.cuda.synchronize()
+    cm.dgmodel.connect_local(dgs)
+    cm.dgmodel.group_rhs(dgs, Ts, Qs, 0.1, 1.0, 0.0)
+    for (_, g, _), T in zip(parts, Ts):
+        Tn = T.cpu().numpy()
+        for i, ge in enumerate(g.topology.globalelems[:g.nreal]):
+            assert rel_linf(Tn[i], ref[int(ge)]) < TOL
+    for d in dgs + [dg1]:
+        d.close()
