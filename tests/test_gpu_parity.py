@@ -562,17 +562,19 @@ def test_stack_height_option_changes_launch_order_only(cm, torch):
     dg.close()
 
 
-def test_tiled_launch_order_on_a_partition(cm, torch):
+@pytest.mark.parametrize("N", [4, 6])
+def test_tiled_launch_order_on_a_partition(cm, torch, N):
     """Tall stacks (18 elements) cut over two ranks of one process: the tiled interior and
-    exterior lists of each rank reproduce the single-rank tendency element by element."""
+    exterior lists of each rank reproduce the single-rank tendency element by element (N = 6:
+    with the two-elements-per-work-group tendency kernel and odd list lengths)."""
     M, BL = cm.mesh, cm.balancelaws
-    rng = [np.linspace(-1, 1, 5), np.linspace(-1, 1, 4), np.linspace(-1, 1, 19)]
+    rng = [np.linspace(-1, 1, 4 if N == 6 else 5), np.linspace(-1, 1, 4), np.linspace(-1, 1, 19)]
     n = np.ones(3) / np.sqrt(3)
 
     def make(rank, size):
         topl = M.StackedBrickTopology(rng, boundary=((1, 2),) * 3, periodicity=(False,) * 3,
                                       rank=rank, size=size)
-        grid = M.DiscontinuousSpectralElementGrid(topl, 4)
+        grid = M.DiscontinuousSpectralElementGrid(topl, N)
         law = BL.AdvectionDiffusion(3, BL.Pseudo1D(n, 1.0, 1 / 100, -1 / 2, 1 / 10),
                                     (BL.InhomogeneousBC(0), BL.InhomogeneousBC(1)))
         return law, grid, cm.dgmodel.DGModel(law, grid)
