@@ -13,6 +13,10 @@ CMDG_K = dict(GRADIENTS=0, DIVGRAD=1, GRADLAP=2, TENDENCY=3, PACK=4, UNPACK=5, U
 STACK_MAXOUT = 8
 OPT_KEEP_GRADFLUX = 1
 OPT_STACK_HEIGHT = 2
+OPT_REFERENCE_HALO = 3
+OPT_HALO_PIPELINE = 4
+CMDG_Q = dict(GRADFLUX_LIVE=1, LAW_NEEDS_GRADFLUX=2, NDERIVED=3, NUPDATED_AUX=4, FUSED_UPDATE_AUX=5,
+              DIRECT_SEND=6, DIRECT_RECV=7, TENDENCY_ELEMS_PER_GROUP=8, HALO_PIPELINE=9)
 
 
 class CmdgStackIntegralDesc(C.Structure):
@@ -102,6 +106,7 @@ SYMBOLS = [
     ("cmdg_lsrk_run", C.c_int, [_vp, _vp, _vp, _d, _d, _i64, _i32, _vp, _vp, _vp]),
     ("cmdg_synchronize", C.c_int, [_vp]),
     ("cmdg_set_option", C.c_int, [_vp, _i32, _i32]),
+    ("cmdg_query", C.c_int, [_vp, _i32, _vp]),
     ("cmdg_halo_begin", C.c_int, [_vp, _vp, _i32]),
     ("cmdg_halo_end", C.c_int, [_vp, _vp, _i32]),
     ("cmdg_fillsendbuf", C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32]),

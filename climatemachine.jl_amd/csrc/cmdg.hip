@@ -68,6 +68,39 @@ static bool load(std::string &err)
 }
 }  // namespace rccl
 
+// ---- roctx, resolved lazily: ranges cost nothing when nobody listens ----------------------
+namespace {
+typedef int (*roctx_push_t)(const char *);
+typedef int (*roctx_pop_t)();
+roctx_push_t g_roctx_push = nullptr;
+roctx_pop_t g_roctx_pop = nullptr;
+int g_roctx_state = 0;  // 0 not tried, 1 available, -1 absent
+void roctx_resolve()
+{
+    g_roctx_state = -1;
+    const char *names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4",
+                           "libroctx64.so", nullptr};
+    const char *want = getenv("CMDG_ROCTX");
+    void *lib = nullptr;
+    for (int i = 0; names[i] && !lib; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
+    if (!lib && want && *want && *want != '0')
+        for (int i = 0; names[i] && !lib; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return;
+    g_roctx_push = (roctx_push_t)dlsym(lib, "roctxRangePushA");
+    g_roctx_pop = (roctx_pop_t)dlsym(lib, "roctxRangePop");
+    if (g_roctx_push && g_roctx_pop) g_roctx_state = 1;
+}
+}  // namespace
+void roctx_push(const char *name)
+{
+    if (g_roctx_state == 0) roctx_resolve();
+    if (g_roctx_state == 1) g_roctx_push(name);
+}
+void roctx_pop()
+{
+    if (g_roctx_state == 1) g_roctx_pop();
+}
+
 // ---------------------------------------------------------------------------------
 EngineBase::~EngineBase()
 {
@@ -91,6 +124,9 @@ EngineBase::~EngineBase()
     if (d_exterior_tiled) hipFree(d_exterior_tiled);
     if (d_faceP) hipFree(d_faceP);
     if (d_faceG) hipFree(d_faceG);
+    if (d_sendoff) hipFree(d_sendoff);
+    if (d_sendent) hipFree(d_sendent);
+    if (d_ghostslot) hipFree(d_ghostslot);
     if (derived) hipFree(derived);
     if (d_partial) hipFree(d_partial);
     if (d_elemred) hipFree(d_elemred);
@@ -99,6 +135,11 @@ EngineBase::~EngineBase()
     if (d_preT) hipFree(d_preT);
     if (d_Dv) hipFree(d_Dv);
     if (ev_comp) hipEventDestroy(ev_comp);
+    if (prof_ext_done) hipEventDestroy(prof_ext_done);
+    for (int i = 0; i < 2; ++i) {
+        if (ev_int[i]) hipEventDestroy(ev_int[i]);
+        if (ev_ext[i]) hipEventDestroy(ev_ext[i]);
+    }
     if (nccl_comm && rccl::CommDestroy) rccl::CommDestroy(nccl_comm);
     if (s_comp) hipStreamDestroy(s_comp);
     if (s_comm) hipStreamDestroy(s_comm);
@@ -154,7 +195,19 @@ int EngineBase::init(const cmdg_desc *d)
     }
     HIPCHK(hipGetDevice(&dev));
     HIPCHK(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&s_comm, hipStreamNonBlocking));
+    {
+        // the halo stream carries the latency chain of a partitioned run (exchange -> exterior
+        // launch -> exchange ...): its small kernels go ahead of the interior launches' blocks
+        int lo = 0, hi = 0;
+        if (communicate() && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
+            HIPCHK(hipStreamCreateWithPriority(&s_comm, hipStreamNonBlocking, hi));
+        else
+            HIPCHK(hipStreamCreateWithFlags(&s_comm, hipStreamNonBlocking));
+    }
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipEventCreateWithFlags(&ev_int[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_ext[i], hipEventDisableTiming));
+    }
     HIPCHK(hipEventCreateWithFlags(&ev_comp, hipEventDisableTiming));
     HIPCHK(hipMalloc(&d_D, sizeof(double) * NQ * NQ));
     HIPCHK(hipMemcpy(d_D, d->D, sizeof(double) * NQ * NQ, hipMemcpyHostToDevice));
@@ -227,7 +280,74 @@ int EngineBase::init(const cmdg_desc *d)
         }
     }
     HIPCHK(hipMalloc(&d_partial, sizeof(double) * 1024));
+    if (communicate())
+        if (int r = init_halo_tables()) return r;
     return init_derived();
+}
+
+// Tables of the exchange without pack / unpack launches (HaloDev).  Whatever cannot be built
+// leaves the corresponding half on the reference's pack / unpack kernels; nothing here fails
+// a create that the reference's tables allow.
+int EngineBase::init_halo_tables()
+{
+    const int64_t NFT = 4 * NQ * NQV + 2 * NQ * NQ;
+    std::vector<int64_t> vs((size_t)nvmapsend), vr((size_t)nvmaprecv), ext((size_t)nexterior);
+    if (nvmapsend) HIPCHK(hipMemcpy(vs.data(), d_vmapsend, sizeof(int64_t) * nvmapsend, hipMemcpyDeviceToHost));
+    if (nvmaprecv) HIPCHK(hipMemcpy(vr.data(), d_vmaprecv, sizeof(int64_t) * nvmaprecv, hipMemcpyDeviceToHost));
+    if (nexterior) HIPCHK(hipMemcpy(ext.data(), d_exterior_user, sizeof(int64_t) * nexterior, hipMemcpyDeviceToHost));
+    // ---- sender: per-element lists of (node, position in vmapsend)
+    bool oks = nvmapsend < 2147483647LL;
+    std::vector<uint8_t> is_ext((size_t)std::max<int64_t>(nreal, 1), 0);
+    for (int64_t e1 : ext)
+        if (e1 >= 1 && e1 <= nreal) is_ext[e1 - 1] = 1;
+    std::vector<int32_t> off((size_t)nreal + 1, 0);
+    for (int64_t i = 0; i < nvmapsend && oks; ++i) {
+        const int64_t id = vs[i] - 1, e = id / Np;
+        if (id < 0 || e >= nreal || !is_ext[e]) oks = false;
+        else off[e + 1] += 1;
+    }
+    if (oks) {
+        for (int64_t e = 0; e < nreal; ++e) off[e + 1] += off[e];
+        std::vector<SendEnt> ent((size_t)std::max<int64_t>(nvmapsend, 1));
+        std::vector<int32_t> fill(off.begin(), off.end() - 1);
+        for (int64_t i = 0; i < nvmapsend; ++i) {
+            const int64_t id = vs[i] - 1, e = id / Np;
+            ent[fill[e]++] = SendEnt{(int32_t)(id - e * Np), (int32_t)i};
+        }
+        HIPCHK(hipMalloc(&d_sendoff, sizeof(int32_t) * off.size()));
+        HIPCHK(hipMalloc(&d_sendent, sizeof(SendEnt) * ent.size()));
+        HIPCHK(hipMemcpy(d_sendoff, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_sendent, ent.data(), sizeof(SendEnt) * ent.size(), hipMemcpyHostToDevice));
+    }
+    direct_send_ok = oks;
+    // ---- receiver: position in vmaprecv of every ghost node
+    const int64_t ng = nghost * Np, g0 = nreal * Np;
+    bool okr = nvmaprecv < 2147483647LL;
+    std::vector<int32_t> gs((size_t)std::max<int64_t>(ng, 1), -1);
+    for (int64_t i = 0; i < nvmaprecv && okr; ++i) {
+        const int64_t id = vr[i] - 1 - g0;
+        if (id < 0 || id >= ng || gs[id] >= 0) okr = false;
+        else gs[id] = (int32_t)i;
+    }
+    if (okr && nreal > 0) {  // every ghost node a face of a real element reads is received
+        std::vector<int32_t> fP((size_t)(nreal * NFT));
+        HIPCHK(hipMemcpy(fP.data(), d_faceP, sizeof(int32_t) * fP.size(), hipMemcpyDeviceToHost));
+        for (size_t q = 0; q < fP.size() && okr; ++q)
+            if (fP[q] >= g0 && (fP[q] - g0 >= ng || gs[fP[q] - g0] < 0)) okr = false;
+    }
+    if (okr) {
+        HIPCHK(hipMalloc(&d_ghostslot, sizeof(int32_t) * gs.size()));
+        HIPCHK(hipMemcpy(d_ghostslot, gs.data(), sizeof(int32_t) * gs.size(), hipMemcpyHostToDevice));
+    }
+    direct_recv_ok = okr;
+    return CMDG_OK;
+}
+
+int EngineBase::before_direct_send(int s, hipStream_t st)
+{
+    if (transport == TRANSPORT_LOCAL && communicate() && direct_send())
+        for (int r : nabrtorank) HIPCHK(hipStreamWaitEvent(st, group[r]->slot[s].ev_pulled, 0));
+    return CMDG_OK;
 }
 
 int EngineBase::ensure_work()
@@ -281,34 +401,44 @@ void EngineBase::prof_collect()
 }
 
 // ---- halo: begin_ghost_exchange! / end_ghost_exchange!  MPIStateArrays.jl:411-483 ----
-int EngineBase::halo_begin(int s, double *array, int nvar)
+int EngineBase::halo_begin(int s, double *array, int nvar, int ncol, bool on_halo_stream)
 {
-    if (int r = halo_pack(s, array, nvar)) return r;
+    if (int r = halo_pack(s, array, nvar, ncol, on_halo_stream)) return r;
     return halo_post(&s, 1);
 }
 
-int EngineBase::halo_pack(int s, double *array, int nvar)
+int EngineBase::halo_pack(int s, double *array, int nvar, int ncol, bool on_halo_stream)
 {
     if (!communicate()) return CMDG_OK;
     if (transport == TRANSPORT_NONE)
         return fail(CMDG_ERR_COMM, "halo exchange needs cmdg_comm_init_rccl or cmdg_comm_connect_local");
+    Range range_("cmdg:halo:pack");
     HaloSlot &h = slot[s];
     if (h.active) return fail(CMDG_ERR_INVALID, "The current ghost exchange must end before another begins.");
     if (nvar > slot_nvar_max) return fail(CMDG_ERR_INVALID, "halo: nstate too large for the buffers");
+    if (ncol == 0) ncol = nvar;
+    if (ncol < nvar) return fail(CMDG_ERR_INVALID, "halo: more packed columns than the array has");
     h.nvar = nvar;
+    h.ncol = ncol;
     h.array = array;
-    // the data to send is produced on the compute stream
-    HIPCHK(hipEventRecord(ev_comp, s_comp));
-    HIPCHK(hipStreamWaitEvent(s_comm, ev_comp, 0));
+    // an exterior launch of this evaluation wrote the nodes of vmapsend already
+    const bool fresh = h.fresh_for == array && h.fresh_nvar == nvar && direct_send();
+    h.fresh_for = nullptr;
+    // the data to send is produced on the compute stream -- unless an exterior launch of the
+    // halo stream's own pipeline wrote it (pipelined())
+    if (!(fresh && on_halo_stream)) {
+        HIPCHK(hipEventRecord(ev_comp, s_comp));
+        HIPCHK(hipStreamWaitEvent(s_comm, ev_comp, 0));
+    }
     if (transport == TRANSPORT_LOCAL) {
         // neighbours must have pulled the previous payload of this slot
         for (int r : nabrtorank) HIPCHK(hipStreamWaitEvent(s_comm, group[r]->slot[s].ev_pulled, 0));
     }
-    if (nvmapsend > 0) {
+    if (nvmapsend > 0 && !fresh) {
         const int64_t n = nvmapsend * nvar;
         prof_begin(CMDG_K_PACK, s_comm);
         hipLaunchKernelGGL(k_fillsendbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s_comm,
-                           h.sendbuf, array, d_vmapsend, nvmapsend, Np, nvar);
+                           h.sendbuf, array, d_vmapsend, nvmapsend, Np, nvar, ncol);
         prof_end(s_comm);
     }
     HIPCHK(hipEventRecord(h.ev_packed, s_comm));
@@ -318,6 +448,7 @@ int EngineBase::halo_pack(int s, double *array, int nvar)
 int EngineBase::halo_post(const int *slots, int nslots)
 {
     if (!communicate()) return CMDG_OK;
+    Range range_("cmdg:halo:transport");
     if (transport == TRANSPORT_RCCL) {
         // one group for everything that begins here: every neighbour pair has its own xGMI
         // link, and one group costs one RCCL launch however many arrays travel
@@ -385,12 +516,16 @@ int EngineBase::set_stack_height(int nv)
 
 void EngineBase::abort_exchanges()
 {
-    for (auto &h : slot) h.active = false;
+    for (auto &h : slot) {
+        h.active = false;
+        h.fresh_for = nullptr;
+    }
 }
 
-int EngineBase::halo_end(int s, double *array, int nvar)
+int EngineBase::halo_end(int s, double *array, int nvar, bool unpack, bool on_halo_stream)
 {
     if (!communicate()) return CMDG_OK;
+    Range range_(unpack ? "cmdg:halo:end+unpack" : "cmdg:halo:end");
     HaloSlot &h = slot[s];
     if (!h.active) return fail(CMDG_ERR_INVALID, "A ghost exchange must begin before it ends.");
     if (h.array != array || h.nvar != nvar)
@@ -414,13 +549,14 @@ int EngineBase::halo_end(int s, double *array, int nvar)
         if (!nabrtorank.empty()) prof_end(s_comm);
         HIPCHK(hipEventRecord(h.ev_pulled, s_comm));
     }
-    if (nvmaprecv > 0) {
+    if (nvmaprecv > 0 && unpack) {
         const int64_t n = nvmaprecv * nvar;
         prof_begin(CMDG_K_UNPACK, s_comm);
         hipLaunchKernelGGL(k_transferrecvbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           s_comm, array, h.recvbuf, d_vmaprecv, nvmaprecv, Np, nvar);
+                           s_comm, array, h.recvbuf, d_vmaprecv, nvmaprecv, Np, nvar, h.ncol);
         prof_end(s_comm);
     }
+    if (on_halo_stream) return CMDG_OK;  // the consumer is the next launch of the halo stream
     HIPCHK(hipEventRecord(h.ev_done, s_comm));
     if (profiling) {
         // exposed time of this exchange: from the moment the compute stream has nothing left to
@@ -449,73 +585,155 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
     const bool gfl = gf_live();  // is state_gradient_flux read by anybody?
     const bool grad = gfl || nhyp > 0;
     const bool hyper = nhyp > 0;
+    // exterior launches write the send buffers / consumers read the receive buffers (HaloDev)
+    const bool dsend = comm && direct_send(), unpack = !(comm && direct_recv());
+    // exterior launches and exchanges on the halo stream, interior launches on the compute stream
+    const bool pipe = pipelined(comm) && !has_hooks;
+    hipStream_t s_ext = pipe ? s_comm : s_comp;
+    // of Qhypervisc_div's nhyp columns the Laplacian pass writes, and the next pass reads, ngl
+    const int nhd = ngl;
     int r;
 #define TRY(x) \
     if ((r = (x)) != CMDG_OK) return r
+    // interior launch I_p of a pass (enqueued before its exterior launch): waits for E_(p-1)
+    auto interior_begin = [&]() -> int {
+        ++pass_seq;
+        if (!pipe) return CMDG_OK;
+        if (profiling && prof_ext_done) {
+            // exposed: the compute stream idle until the previous exterior launch is done
+            ProfRec pr;
+            pr.kernel = CMDG_K_HALO_EXPOSED;
+            pr.clamp = true;
+            hipEventCreate(&pr.e0);
+            hipEventRecord(pr.e0, s_comp);
+            pr.e1 = prof_ext_done;
+            prof_ext_done = nullptr;
+            prof.push_back(pr);
+        }
+        HIPCHK(hipStreamWaitEvent(s_comp, ev_ext[(pass_seq - 1) & 1], 0));
+        return CMDG_OK;
+    };
+    auto interior_end = [&]() -> int {
+        if (pipe) HIPCHK(hipEventRecord(ev_int[pass_seq & 1], s_comp));
+        return CMDG_OK;
+    };
+    // exterior launch E_p: waits for I_(p-1)
+    auto exterior_begin = [&]() -> int {
+        if (pipe) HIPCHK(hipStreamWaitEvent(s_comm, ev_int[(pass_seq - 1) & 1], 0));
+        return CMDG_OK;
+    };
+    auto exterior_end = [&]() -> int {
+        if (pipe) HIPCHK(hipEventRecord(ev_ext[pass_seq & 1], s_comm));
+        if (pipe && profiling) {
+            if (prof_ext_done) hipEventDestroy(prof_ext_done);
+            hipEventCreate(&prof_ext_done);
+            hipEventRecord(prof_ext_done, s_comm);
+        }
+        return CMDG_OK;
+    };
     switch (seg) {
     case 0:
-        if (has_hooks) TRY(run_pre_hooks(c));  // update_auxiliary_state!(realelems) of the law
+        if (has_hooks) {
+            TRY(run_pre_hooks(c));  // update_auxiliary_state!(realelems) of the law
+            slot[SLOT_Q].fresh_for = nullptr;  // (its filters rewrite Q)
+        }
         if (!(grad && fused_update_aux())) launch_update_aux(c, 0, nreal);
-        if (comm) TRY(halo_begin(SLOT_Q, c.Qin, ns));
-        if (grad) launch_gradients(c, d_interior, ninterior);
+        if (comm) TRY(halo_begin(SLOT_Q, c.Qin, ns, 0, pipe));
+        if (grad) {
+            TRY(interior_begin());
+            launch_gradients(c, d_interior, ninterior, false, s_comp);
+            TRY(interior_end());
+        }
         break;
     case 1:
         if (!grad) break;
         if (comm) {
-            TRY(halo_end(SLOT_Q, c.Qin, ns));
-            launch_update_aux(c, nreal, nelem);
+            TRY(halo_end(SLOT_Q, c.Qin, ns, unpack, pipe));
+            if (unpack) launch_update_aux(c, nreal, nelem);
             // update_auxiliary_state!(ghostelems): the flow deviation of the ghost stacks
             if (has_hooks && hooks.has_flow_deviation)
                 TRY(flow_deviation(c.Qin, nreal / hooks.nvertelem, nghost / hooks.nvertelem));
         }
-        launch_gradients(c, d_exterior, nexterior);
+        if (dsend && gfl) TRY(before_direct_send(SLOT_GF, s_ext));
+        if (dsend && hyper) TRY(before_direct_send(SLOT_HG, s_ext));
+        TRY(exterior_begin());
+        launch_gradients(c, d_exterior, nexterior, comm, s_ext);
+        TRY(exterior_end());
+        if (dsend && gfl && !gradient_filter) mark_fresh(SLOT_GF, gf, ngf);
+        if (dsend && hyper) mark_fresh(SLOT_HG, hypgrad, 3 * ngl);
         if (gradient_filter && gfl) TRY(filter_apply(gradient_filter, gf, ngf));  // (:185-193)
         if (comm) {  // both begin here: packed back to back, posted in one group
             int slots[2], ns_ = 0;
             if (gfl) {
-                TRY(halo_pack(SLOT_GF, gf, ngf));
+                TRY(halo_pack(SLOT_GF, gf, ngf, 0, pipe));
                 slots[ns_++] = SLOT_GF;
             }
             if (hyper) {
-                TRY(halo_pack(SLOT_HG, hypgrad, 3 * ngl));
+                TRY(halo_pack(SLOT_HG, hypgrad, 3 * ngl, 0, pipe));
                 slots[ns_++] = SLOT_HG;
             }
             if (ns_) TRY(halo_post(slots, ns_));
         }
         // update_auxiliary_state_gradient!(realelems)  (DGModel.jl:210-222)
         if (has_hooks && gfl) TRY(run_gradient_hooks(c, 0, nreal));
-        if (hyper) launch_divgrad(c, d_interior, ninterior);
+        if (hyper) {
+            TRY(interior_begin());
+            launch_divgrad(c, d_interior, ninterior, false, s_comp);
+            TRY(interior_end());
+        }
         break;
     case 2:
         if (!hyper) break;
-        if (comm) TRY(halo_end(SLOT_HG, hypgrad, 3 * ngl));
-        launch_divgrad(c, d_exterior, nexterior);
-        if (comm) TRY(halo_begin(SLOT_HD, hypdiv, nhyp));
-        launch_gradlap(c, d_interior, ninterior);
+        if (comm) TRY(halo_end(SLOT_HG, hypgrad, 3 * ngl, unpack, pipe));
+        if (dsend) TRY(before_direct_send(SLOT_HD, s_ext));
+        TRY(exterior_begin());
+        launch_divgrad(c, d_exterior, nexterior, comm, s_ext);
+        TRY(exterior_end());
+        if (dsend) mark_fresh(SLOT_HD, hypdiv, nhd);
+        if (comm) TRY(halo_begin(SLOT_HD, hypdiv, nhd, nhyp, pipe));
+        TRY(interior_begin());
+        launch_gradlap(c, d_interior, ninterior, false, s_comp);
+        TRY(interior_end());
         break;
     case 3:
         if (hyper) {
-            if (comm) TRY(halo_end(SLOT_HD, hypdiv, nhyp));
-            launch_gradlap(c, d_exterior, nexterior);
-            if (comm) TRY(halo_begin(SLOT_HG, hypgrad, 3 * ngl));
+            if (comm) TRY(halo_end(SLOT_HD, hypdiv, nhd, unpack, pipe));
+            if (dsend) TRY(before_direct_send(SLOT_HG, s_ext));
+            TRY(exterior_begin());
+            launch_gradlap(c, d_exterior, nexterior, comm, s_ext);
+            TRY(exterior_end());
+            if (dsend) mark_fresh(SLOT_HG, hypgrad, 3 * ngl);
+            if (comm) TRY(halo_begin(SLOT_HG, hypgrad, 3 * ngl, 0, pipe));
         }
-        launch_tendency(c, d_interior, ninterior);
+        TRY(interior_begin());
+        launch_tendency(c, d_interior, ninterior, false, s_comp);
+        TRY(interior_end());
         break;
-    case 4:
+    case 4:  // the exchanges the tendency pass waits for end here, on every rank of a local group,
+             // before any rank's exterior launch overwrites a send buffer (case 5)
         if (comm) {
             if (grad) {
                 if (gfl) {
-                    TRY(halo_end(SLOT_GF, gf, ngf));
+                    TRY(halo_end(SLOT_GF, gf, ngf, unpack, pipe));
                     // update_auxiliary_state_gradient!(ghostelems)  (DGModel.jl:355-361)
                     if (has_hooks) TRY(run_gradient_hooks(c, nreal, nelem));
                 }
-                if (hyper) TRY(halo_end(SLOT_HG, hypgrad, 3 * ngl));
+                if (hyper) TRY(halo_end(SLOT_HG, hypgrad, 3 * ngl, unpack, pipe));
             } else {
-                TRY(halo_end(SLOT_Q, c.Qin, ns));
-                launch_update_aux(c, nreal, nelem);
+                TRY(halo_end(SLOT_Q, c.Qin, ns, unpack, pipe));
+                if (unpack) launch_update_aux(c, nreal, nelem);
             }
         }
-        launch_tendency(c, d_exterior, nexterior);
+        break;
+    case 5:
+        if (dsend && c.lsrk) TRY(before_direct_send(SLOT_Q, s_ext));
+        TRY(exterior_begin());
+        launch_tendency(c, d_exterior, nexterior, comm, s_ext);
+        TRY(exterior_end());
+        if (dsend && c.lsrk) mark_fresh(SLOT_Q, c.Qout, ns);
+        // whatever follows on the compute stream (a filter, the caller's next call, the next
+        // evaluation's first interior launch) finds this evaluation complete
+        if (pipe) HIPCHK(hipStreamWaitEvent(s_comp, ev_ext[pass_seq & 1], 0));
         if (tendency_filter) TRY(filter_apply(tendency_filter, c.tendency, ns));  // (:417-425)
         if (c.update_after) {
             const int64_t n = (int64_t)Np * ns * nreal;
@@ -535,6 +753,7 @@ int EngineBase::rhs_async(const RhsCtx &c)
 {
     if (transport == TRANSPORT_LOCAL && communicate())
         return fail(CMDG_ERR_INVALID, "handles connected locally must be driven by the cmdg_group_* calls");
+    invalidate_sends();  // the caller's Q: nothing is known about its send buffer
     for (int s = 0; s < NSEG; ++s)
         if (int r = rhs_segment(s, c)) {
             abort_exchanges();
@@ -553,17 +772,21 @@ static void lsrk_stage_buffers(EngineBase *e, double *Q, int s, int nstages, dou
 }
 
 int EngineBase::lsrk_step(double *Q, double *dQ, double t, double dt, int nstages,
-                          const double *rka, const double *rkb, const double *rkc)
+                          const double *rka, const double *rkb, const double *rkc, bool continued)
 {
     std::vector<EngineBase *> one{this};
     double *Qs[1] = {Q}, *dQs[1] = {dQ};
     if (transport == TRANSPORT_LOCAL && communicate())
         return fail(CMDG_ERR_INVALID, "handles connected locally must be driven by the cmdg_group_* calls");
-    return group_lsrk_step(one, Qs, dQs, t, dt, nstages, rka, rkb, rkc);
+    return group_lsrk_step(one, Qs, dQs, t, dt, nstages, rka, rkb, rkc, continued);
 }
 
-int group_rhs(std::vector<EngineBase *> &g, std::vector<RhsCtx> &c)
+// keep_fresh: the state read is what the previous stage's fused update wrote (its exterior launch
+// filled the send buffer of Q already); otherwise nothing is known about the send buffers
+int group_rhs(std::vector<EngineBase *> &g, std::vector<RhsCtx> &c, bool keep_fresh)
 {
+    if (!keep_fresh)
+        for (auto *e : g) e->invalidate_sends();
     for (int s = 0; s < EngineBase::NSEG; ++s)
         for (size_t i = 0; i < g.size(); ++i)
             if (int r = g[i]->rhs_segment(s, c[i])) {
@@ -573,8 +796,10 @@ int group_rhs(std::vector<EngineBase *> &g, std::vector<RhsCtx> &c)
     return CMDG_OK;
 }
 
+// continued: this step follows the previous step of the same run with nothing in between
 int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, double t, double dt,
-                    int nstages, const double *rka, const double *rkb, const double *rkc)
+                    int nstages, const double *rka, const double *rkb, const double *rkc,
+                    bool continued)
 {
     if (nstages < 1) return g[0]->fail(CMDG_ERR_INVALID, "lsrk: nstages < 1");
     for (auto *e : g)
@@ -601,7 +826,7 @@ int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, doubl
             x.rkb_dt = rkb[s] * dt;
             x.rka_next = rka[(s + 1) % nstages];
         }
-        if (int r = group_rhs(g, c)) return r;
+        if (int r = group_rhs(g, c, s > 0 || continued)) return r;
     }
     for (size_t i = 0; i < g.size(); ++i) {
         EngineBase *e = g[i];
@@ -610,8 +835,10 @@ int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, doubl
                                hipMemcpyDeviceToDevice, e->s_comp) != hipSuccess)
                 return e->fail(CMDG_ERR_HIP, "lsrk: copy back failed");
         // user callback EveryXSimulationSteps(1) of heldsuarez.jl:261-272
-        if (e->step_filter)
+        if (e->step_filter) {
             if (int r = e->filter_apply(e->step_filter, Q[i], e->ns)) return r;
+            e->invalidate_sends();
+        }
     }
     return CMDG_OK;
 }
@@ -1186,7 +1413,7 @@ int cmdg_lsrk_run(cmdg_handle h, double *Q, double *dQ, double t, double dt, int
     if (!h || !Q || !dQ || !rka || !rkb || !rkc) return CMDG_ERR_INVALID;
     DevGuard guard_(h->eng);
     for (int64_t i = 0; i < nsteps; ++i) {
-        int r = h->eng->lsrk_step(Q, dQ, t + i * dt, dt, nstages, rka, rkb, rkc);
+        int r = h->eng->lsrk_step(Q, dQ, t + i * dt, dt, nstages, rka, rkb, rkc, i > 0);
         if (r) return set_err(h, r);
     }
     return CMDG_OK;
@@ -1207,7 +1434,36 @@ int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value)
     switch (option) {
     case CMDG_OPT_KEEP_GRADFLUX: e->keep_gradflux = value != 0; return CMDG_OK;
     case CMDG_OPT_STACK_HEIGHT: return set_err(h, e->set_stack_height(value));
+    case CMDG_OPT_REFERENCE_HALO:
+        if (int r = e->synchronize()) return set_err(h, r);
+        e->reference_halo = value != 0;
+        e->invalidate_sends();
+        return CMDG_OK;
+    case CMDG_OPT_HALO_PIPELINE:
+        if (int r = e->synchronize()) return set_err(h, r);
+        e->no_pipeline = value == 0;
+        return CMDG_OK;
     default: return set_err(h, e->fail(CMDG_ERR_INVALID, "cmdg_set_option: unknown option"));
+    }
+}
+
+int cmdg_query(cmdg_handle h, int32_t what, int64_t *out)
+{
+    if (!h || !out) return CMDG_ERR_INVALID;
+    const EngineBase *e = h->eng;
+    switch (what) {
+    case CMDG_Q_GRADFLUX_LIVE: *out = e->gf_live(); return CMDG_OK;
+    case CMDG_Q_LAW_NEEDS_GRADFLUX: *out = e->law_needs_gradflux(); return CMDG_OK;
+    case CMDG_Q_NDERIVED: *out = e->law_nder(); return CMDG_OK;
+    case CMDG_Q_NUPDATED_AUX: *out = e->has_update_aux() ? e->law_nupd() : 0; return CMDG_OK;
+    case CMDG_Q_FUSED_UPDATE_AUX: *out = e->has_update_aux() && e->fused_update_aux(); return CMDG_OK;
+    case CMDG_Q_DIRECT_SEND: *out = e->communicate() && e->direct_send(); return CMDG_OK;
+    case CMDG_Q_DIRECT_RECV: *out = e->communicate() && e->direct_recv(); return CMDG_OK;
+    case CMDG_Q_TENDENCY_ELEMS_PER_GROUP: *out = e->tendency_epb(); return CMDG_OK;
+    case CMDG_Q_HALO_PIPELINE:
+        *out = e->pipelined(e->communicate() && !(e->stacked && e->direction == DIR_VERTICAL)) && !e->has_hooks;
+        return CMDG_OK;
+    default: return set_err(h, h->eng->fail(CMDG_ERR_INVALID, "cmdg_query: unknown item"));
     }
 }
 
@@ -1231,7 +1487,7 @@ int cmdg_fillsendbuf(double *sendbuf, const double *buf, const int64_t *vmapsend
     if (nvmap == 0) return CMDG_OK;
     const int64_t n = nvmap * nstate;
     hipLaunchKernelGGL(k_fillsendbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, sendbuf, buf,
-                       vmapsend, nvmap, Np, nstate);
+                       vmapsend, nvmap, Np, nstate, nstate);
     return hipGetLastError() == hipSuccess && hipStreamSynchronize(0) == hipSuccess ? CMDG_OK : CMDG_ERR_HIP;
 }
 
@@ -1242,7 +1498,7 @@ int cmdg_transferrecvbuf(double *buf, const double *recvbuf, const int64_t *vmap
     if (nvmap == 0) return CMDG_OK;
     const int64_t n = nvmap * nstate;
     hipLaunchKernelGGL(k_transferrecvbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, buf,
-                       recvbuf, vmaprecv, nvmap, Np, nstate);
+                       recvbuf, vmaprecv, nvmap, Np, nstate, nstate);
     return hipGetLastError() == hipSuccess && hipStreamSynchronize(0) == hipSuccess ? CMDG_OK : CMDG_ERR_HIP;
 }
 
@@ -1380,7 +1636,7 @@ int cmdg_group_lsrk_run(cmdg_handle *handles, int32_t n, double **Q, double **dQ
     std::vector<EngineBase *> g;
     for (int i = 0; i < n; ++i) g.push_back(handles[i]->eng);
     for (int64_t s = 0; s < nsteps; ++s) {
-        int r = group_lsrk_step(g, Q, dQ, t + s * dt, dt, nstages, rka, rkb, rkc);
+        int r = group_lsrk_step(g, Q, dQ, t + s * dt, dt, nstages, rka, rkb, rkc, s > 0);
         if (r) {
             for (int i = 0; i < n; ++i) set_err(handles[i], r);
             return r;

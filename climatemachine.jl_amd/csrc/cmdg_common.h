@@ -39,6 +39,28 @@ struct GridDev {
     const double *faceG;
 };
 
+// Ghost exchange without pack / unpack launches (handles with neighbours; every pointer is NULL
+// otherwise).  The wire format is the reference's (nstate, nvmap) state-fastest buffer of
+// kernel_fillsendbuf! / kernel_transferrecvbuf! (MPIStateArrays.jl:837-871).
+//   sender:   the exterior launch of a pass copies the element's nodes of vmapsend out of LDS into
+//             the send buffer of every array it produces (the nodes of vmapsend all belong to
+//             exterior elements, Topologies.jl:250-251);
+//   receiver: the plus side of a face whose neighbour is a ghost element is read from the receive
+//             buffer of the array instead of from the ghost element.
+struct SendEnt {
+    int32_t node;  // node of the element, 0-based
+    int32_t pos;   // position in vmapsend, 0-based
+};
+struct HaloDev {
+    const int32_t *sendoff;    // (nreal + 1) CSR over the real elements; NULL: this launch sends nothing
+    const SendEnt *sendent;    // ascending position within an element
+    double *send[2];           // send buffers of this pass's outputs (NULL: not exchanged)
+    const int32_t *ghostslot;  // (nghost * Np) position in vmaprecv of a ghost node; NULL: the ghost
+                               // elements hold the data (exchanges are unpacked)
+    const double *recvQ, *recvGF, *recvHG, *recvHD;
+    int64_t nreal;
+};
+
 // NQ = horizontal points per direction, NQV = vertical ones (polynomialorder = (N_h, N_v);
 // reference: `info.Nq`, `info.Nqk`, `Nfp_h`, `Nfp_v` of basic_grid_info, SpaceDiscretization.jl:18-60)
 template <int NQ, int NQV = NQ>
@@ -102,6 +124,43 @@ __device__ __forceinline__ void load_state(Vec<NVAR> &dst, const double *__restr
 {
 #pragma unroll
     for (int s = 0; s < NVAR; ++s) dst[s] = arr[ijk + (int64_t)Np * (s + (int64_t)NVAR * e)];
+}
+
+// position in vmaprecv of the plus-side node (eP, vidP), -1 when it is read from its element
+template <int Np>
+__device__ __forceinline__ int ghost_slot(const HaloDev &h, int64_t eP, int vidP)
+{
+    return (h.ghostslot != nullptr && eP >= h.nreal) ? h.ghostslot[(eP - h.nreal) * Np + vidP] : -1;
+}
+// the first NLOAD of the NVAR columns of the plus-side node: from its element, or from the
+// receive buffer of the array (gslot >= 0), whose positions hold NVR columns
+template <int NVAR, int Np, int NLOAD, int NVR = NVAR>
+__device__ __forceinline__ void load_plus(Vec<NLOAD> &dst, const double *__restrict__ arr,
+                                          const double *__restrict__ recv, int gslot, int vidP,
+                                          int64_t eP)
+{
+    if (gslot >= 0) {
+#pragma unroll
+        for (int s = 0; s < NLOAD; ++s) dst[s] = recv[s + (int64_t)NVR * gslot];
+    } else {
+#pragma unroll
+        for (int s = 0; s < NLOAD; ++s) dst[s] = arr[vidP + (int64_t)Np * (s + (int64_t)NVAR * eP)];
+    }
+}
+// exterior launches: the element's nodes of vmapsend into send buffer `which` (NVAR columns per
+// position, the first NW written); value(s, node) is the value the pass stores for the node
+template <int NVAR, int NW, class F>
+__device__ __forceinline__ void send_nodes(const HaloDev &h, int which, int64_t e, int tid,
+                                           int nthreads, F value)
+{
+    if (h.sendoff == nullptr || h.send[which] == nullptr) return;
+    const int b1 = h.sendoff[e + 1];
+    for (int k = h.sendoff[e] + tid; k < b1; k += nthreads) {
+        const SendEnt ent = h.sendent[k];
+        double *dst = h.send[which] + (int64_t)NVAR * ent.pos;
+#pragma unroll
+        for (int s = 0; s < NW; ++s) dst[s] = value(s, ent.node);
+    }
 }
 
 }  // namespace cmdg

@@ -22,8 +22,13 @@ struct HaloSlot {
     double *sendbuf = nullptr, *recvbuf = nullptr;
     hipEvent_t ev_packed = nullptr, ev_done = nullptr, ev_pulled = nullptr;
     bool active = false;  // begin issued, end pending
-    int nvar = 0;
+    int nvar = 0;         // columns per position of the packed buffers
+    int ncol = 0;         // columns of the array (>= nvar: the leading nvar travel)
     double *array = nullptr;
+    // the array whose nodes of vmapsend an exterior launch has already written to sendbuf
+    // (halo_pack then launches nothing); NULL: sendbuf is stale
+    const double *fresh_for = nullptr;
+    int fresh_nvar = 0;
 };
 
 struct RhsCtx {
@@ -43,6 +48,18 @@ struct FilterObj {
     int indices[CMDG_MAX_FILTER_STATES] = {0};
     int aux_ref_rho = 0, aux_ref_rhoe = 0;
     double *d_Fh = nullptr, *d_Fv = nullptr;
+};
+
+// roctx range around the host-side enqueue of a phase (the reference instruments the same five
+// halo phases with NVTX, MPIStateArrays.jl:419-439,465-480): a no-op unless the roctx library is
+// in the process (rocprofv3 --marker-trace) or CMDG_ROCTX=1 asks for it to be loaded
+void roctx_push(const char *name);
+void roctx_pop();
+struct Range {
+    explicit Range(const char *name) { roctx_push(name); }
+    ~Range() { roctx_pop(); }
+    Range(const Range &) = delete;
+    Range &operator=(const Range &) = delete;
 };
 
 struct ProfRec {
@@ -104,11 +121,12 @@ struct EngineBase {
     }
     bool communicate() const { return !nabrtorank.empty(); }
 
-    // physics / order specific launches
-    virtual void launch_gradients(const RhsCtx &c, const int64_t *elems, int64_t n) = 0;
-    virtual void launch_divgrad(const RhsCtx &c, const int64_t *elems, int64_t n) = 0;
-    virtual void launch_gradlap(const RhsCtx &c, const int64_t *elems, int64_t n) = 0;
-    virtual void launch_tendency(const RhsCtx &c, const int64_t *elems, int64_t n) = 0;
+    // physics / order specific launches; `exterior`: the launch of the exterior element list of a
+    // handle with neighbours (writes the send buffers of what it produces, see HaloDev)
+    virtual void launch_gradients(const RhsCtx &c, const int64_t *elems, int64_t n, bool exterior, hipStream_t st) = 0;
+    virtual void launch_divgrad(const RhsCtx &c, const int64_t *elems, int64_t n, bool exterior, hipStream_t st) = 0;
+    virtual void launch_gradlap(const RhsCtx &c, const int64_t *elems, int64_t n, bool exterior, hipStream_t st) = 0;
+    virtual void launch_tendency(const RhsCtx &c, const int64_t *elems, int64_t n, bool exterior, hipStream_t st) = 0;
     virtual void launch_update_aux(const RhsCtx &c, int64_t e0, int64_t e1) = 0;
     virtual bool has_update_aux() const = 0;
     virtual bool law_needs_gradflux() const = 0;
@@ -119,23 +137,99 @@ struct EngineBase {
         return ngf > 0 && (keep_gradflux || law_needs_gradflux() || has_hooks || gradient_filter);
     }
     virtual bool fused_update_aux() const = 0;
+    // introspection (cmdg_query): per-node columns of the law's time-invariant derived fields,
+    // auxiliary columns its nodal refresh rewrites, elements per work-group of the tendency pass
+    virtual int law_nder() const = 0;
+    virtual int law_nupd() const = 0;
+    virtual int tendency_epb() const = 0;
     virtual int init_derived() = 0;
     // mode 0: per-element minimum node distance, mode 1: per-element maximum Courant number
     virtual int launch_courant(int mode, int kind, const double *Q, double dt, double t, int dir,
                                double *out_elem) = 0;
 
+    // ---- ghost exchange without pack / unpack launches (HaloDev, cmdg_common.h) -------------
+    // tables built at create from vmapsend / vmaprecv / the digested face table; *_ok = they
+    // could be built (every node of vmapsend in an exterior element, every ghost node received
+    // once, every ghost node a face reads received)
+    int32_t *d_sendoff = nullptr, *d_ghostslot = nullptr;
+    SendEnt *d_sendent = nullptr;
+    bool direct_send_ok = false, direct_recv_ok = false;
+    bool reference_halo = false;  // CMDG_OPT_REFERENCE_HALO: pack and unpack as the reference does
+    int init_halo_tables();
+    bool direct_send() const { return direct_send_ok && !reference_halo; }
+    // consumers may read the receive buffers unless somebody reads the ghost ELEMENTS of Q: a
+    // nodal update_auxiliary_state! of the ghosts that is not fused away, or the hooks
+    bool direct_recv() const
+    {
+        return direct_recv_ok && !reference_halo && !has_hooks && !(has_update_aux() && !fused_update_aux());
+    }
+    // what a launch is handed: receive side for every launch, send side for exterior ones
+    HaloDev halo_dev(bool exterior, double *send0, double *send1) const
+    {
+        HaloDev h{};
+        h.nreal = nreal;
+        if (!communicate()) return h;
+        if (exterior && direct_send()) {
+            h.sendoff = d_sendoff;
+            h.sendent = d_sendent;
+            h.send[0] = send0;
+            h.send[1] = send1;
+        }
+        if (direct_recv()) {
+            h.ghostslot = d_ghostslot;
+            h.recvQ = slot[SLOT_Q].recvbuf;
+            h.recvGF = slot[SLOT_GF].recvbuf;
+            h.recvHG = slot[SLOT_HG].recvbuf;
+            h.recvHD = slot[SLOT_HD].recvbuf;
+        }
+        return h;
+    }
+    // an exterior launch (on stream st) is about to overwrite sendbuf of slot s: with the local
+    // transport the neighbours must have pulled its previous payload
+    int before_direct_send(int s, hipStream_t st);
+    // ---- two pipelines (handles with neighbours whose exchanges run direct both ways) ---------
+    // The exterior launches E_p of the passes and the exchanges X_p they feed form a serial chain
+    // X_p -> E_p -> X_(p+1) -> E_(p+1) ...; it runs on the halo stream with no event hop inside,
+    // while the interior launches I_p run on the compute stream.  A pass reads what the previous
+    // pass wrote for the element and its face neighbours, so I_p waits for E_(p-1) and E_p waits
+    // for I_(p-1) (events of alternating parity): the interior work of a pass hides the exchanges
+    // of two, and a step costs max(chain, compute) instead of the sum over passes of
+    // max(I_p, X_p) + E_p.
+    hipEvent_t ev_int[2] = {nullptr, nullptr}, ev_ext[2] = {nullptr, nullptr};
+    int64_t pass_seq = 0;  // passes started on this handle
+    hipEvent_t prof_ext_done = nullptr;  // profiling: end of the last exterior launch
+    bool no_pipeline = false;  // CMDG_OPT_HALO_PIPELINE = 0
+    bool pipelined(bool comm) const
+    {
+        return comm && !no_pipeline && direct_send() && direct_recv() && !gradient_filter &&
+               !tendency_filter && (!has_update_aux() || fused_update_aux());
+    }
+    void invalidate_sends()
+    {
+        for (auto &h : slot) h.fresh_for = nullptr;
+    }
+    void mark_fresh(int s, const double *array, int nvar)
+    {
+        slot[s].fresh_for = array;
+        slot[s].fresh_nvar = nvar;
+    }
+
     // orchestration
-    static constexpr int NSEG = 5;
+    static constexpr int NSEG = 6;
     int rhs_segment(int seg, const RhsCtx &c);
     int rhs_async(const RhsCtx &c);
     int lsrk_step(double *Q, double *dQ, double t, double dt, int nstages, const double *rka,
-                  const double *rkb, const double *rkc);
-    int halo_begin(int s, double *array, int nvar);
+                  const double *rkb, const double *rkc, bool continued = false);
+    // (nvar columns per packed position = the leading columns of the ncol-column array; ncol = 0:
+    // the whole array, nvar == ncol, as the reference packs)
+    // on_halo_stream (pipelined()): producer and consumer are launches of the halo stream itself
+    int halo_begin(int s, double *array, int nvar, int ncol = 0, bool on_halo_stream = false);
     // begin_ghost_exchange! in two halves, so that exchanges that begin at the same point of an
     // evaluation are packed one after the other and posted in ONE RCCL group
-    int halo_pack(int s, double *array, int nvar);
+    int halo_pack(int s, double *array, int nvar, int ncol = 0, bool on_halo_stream = false);
     int halo_post(const int *slots, int nslots);
-    int halo_end(int s, double *array, int nvar);
+    // unpack = false: the consumers read the receive buffer (direct_recv())
+    int halo_end(int s, double *array, int nvar, bool unpack = true, bool on_halo_stream = false);
     void abort_exchanges();  // after a failed call: no exchange is left "begun"
     int ensure_work();
     int synchronize();
@@ -197,9 +291,10 @@ struct DevGuard {
 
 namespace cmdg {
 
-int group_rhs(std::vector<EngineBase *> &g, std::vector<RhsCtx> &c);
+int group_rhs(std::vector<EngineBase *> &g, std::vector<RhsCtx> &c, bool keep_fresh = false);
 int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, double t, double dt,
-                    int nstages, const double *rka, const double *rkb, const double *rkc);
+                    int nstages, const double *rka, const double *rkb, const double *rkc,
+                    bool continued = false);
 
 // ---------------------------------------------------------------------------------
 template <class P, int NQ_, int NQV_ = NQ_>
@@ -229,40 +324,53 @@ struct EngineT : EngineBase {
         a.direction = dir;
         a.model_dir = direction;
         a.nf_first = nf_first;
+        a.h = HaloDev{};
+        a.h.nreal = nreal;
         return a;
     }
-    void launch_gradients(const RhsCtx &c, const int64_t *elems, int64_t n) override
+    void launch_gradients(const RhsCtx &c, const int64_t *elems, int64_t n, bool exterior, hipStream_t st) override
     {
         if (n <= 0) return;
-        prof_begin(CMDG_K_GRADIENTS, s_comp);
+        Range range_(exterior ? "cmdg:gradients:exterior" : "cmdg:gradients");
+        prof_begin(CMDG_K_GRADIENTS, st);
+        PassArgs<P> args = make_args(c, elems, n, diffusion_direction);
+        args.h = halo_dev(exterior, gf_live() ? slot[SLOT_GF].sendbuf : nullptr,
+                          ngl > 0 ? slot[SLOT_HG].sendbuf : nullptr);
         if (gf_live())
             hipLaunchKernelGGL((k_gradients<P, NQ_, NQV_, true>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0,
-                               s_comp, make_args(c, elems, n, diffusion_direction));
+                               st, args);
         else
             hipLaunchKernelGGL((k_gradients<P, NQ_, NQV_, false>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0,
-                               s_comp, make_args(c, elems, n, diffusion_direction));
-        prof_end(s_comp);
+                               st, args);
+        prof_end(st);
     }
-    void launch_divgrad(const RhsCtx &c, const int64_t *elems, int64_t n) override
+    void launch_divgrad(const RhsCtx &c, const int64_t *elems, int64_t n, bool exterior, hipStream_t st) override
     {
         if (n <= 0) return;
-        prof_begin(CMDG_K_DIVGRAD, s_comp);
-        hipLaunchKernelGGL((k_divgrad<P, NQ_, NQV_>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0, s_comp,
-                           make_args(c, elems, n, diffusion_direction));
-        prof_end(s_comp);
+        Range range_(exterior ? "cmdg:divgrad:exterior" : "cmdg:divgrad");
+        prof_begin(CMDG_K_DIVGRAD, st);
+        PassArgs<P> args = make_args(c, elems, n, diffusion_direction);
+        args.h = halo_dev(exterior, slot[SLOT_HD].sendbuf, nullptr);
+        hipLaunchKernelGGL((k_divgrad<P, NQ_, NQV_>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0, st,
+                           args);
+        prof_end(st);
     }
-    void launch_gradlap(const RhsCtx &c, const int64_t *elems, int64_t n) override
+    void launch_gradlap(const RhsCtx &c, const int64_t *elems, int64_t n, bool exterior, hipStream_t st) override
     {
         if (n <= 0) return;
-        prof_begin(CMDG_K_GRADLAP, s_comp);
-        hipLaunchKernelGGL((k_gradlap<P, NQ_, NQV_>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0, s_comp,
-                           make_args(c, elems, n, diffusion_direction));
-        prof_end(s_comp);
+        Range range_(exterior ? "cmdg:gradlap:exterior" : "cmdg:gradlap");
+        prof_begin(CMDG_K_GRADLAP, st);
+        PassArgs<P> args = make_args(c, elems, n, diffusion_direction);
+        args.h = halo_dev(exterior, slot[SLOT_HG].sendbuf, nullptr);
+        hipLaunchKernelGGL((k_gradlap<P, NQ_, NQV_>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0, st,
+                           args);
+        prof_end(st);
     }
-    void launch_tendency(const RhsCtx &c, const int64_t *elems, int64_t n) override
+    void launch_tendency(const RhsCtx &c, const int64_t *elems, int64_t n, bool exterior, hipStream_t st) override
     {
         if (n <= 0) return;
-        prof_begin(CMDG_K_TENDENCY, s_comp);
+        Range range_(exterior ? "cmdg:tendency:exterior" : "cmdg:tendency");
+        prof_begin(CMDG_K_TENDENCY, st);
 #ifdef CMDG_GF_ALWAYS
         const bool gfl = true;
 #else
@@ -270,19 +378,20 @@ struct EngineT : EngineBase {
 #endif
         using SH = TendencyShape<P, NQ_, NQV_>;
         const dim3 grid((unsigned)SH::blocks(n)), block(SH::NT);
-        const PassArgs<P> args = make_args(c, elems, n, direction);
+        PassArgs<P> args = make_args(c, elems, n, direction);
+        args.h = halo_dev(exterior, c.lsrk ? slot[SLOT_Q].sendbuf : nullptr, nullptr);
         if (c.lsrk) {
             if (gfl)
-                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, true, true>), grid, block, 0, s_comp, args);
+                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, true, true>), grid, block, 0, st, args);
             else
-                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, true, false>), grid, block, 0, s_comp, args);
+                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, true, false>), grid, block, 0, st, args);
         } else {
             if (gfl)
-                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, false, true>), grid, block, 0, s_comp, args);
+                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, false, true>), grid, block, 0, st, args);
             else
-                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, false, false>), grid, block, 0, s_comp, args);
+                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, false, false>), grid, block, 0, st, args);
         }
-        prof_end(s_comp);
+        prof_end(st);
     }
     void launch_update_aux(const RhsCtx &c, int64_t e0, int64_t e1) override
     {
@@ -312,6 +421,9 @@ struct EngineT : EngineBase {
     bool has_update_aux() const override { return P::HAS_UPDATE_AUX && P::update_aux_active(prm); }
     bool law_needs_gradflux() const override { return P::needs_gradflux(prm); }
     bool fused_update_aux() const override { return P::HAS_UPDATE_AUX && P::FUSE_UPDATE_AUX; }
+    int law_nder() const override { return P::HAS_SOURCE ? P::NDER : 0; }
+    int law_nupd() const override { return P::HAS_UPDATE_AUX ? P::NUPD : 0; }
+    int tendency_epb() const override { return TendencyShape<P, NQ_, NQV_>::EPB; }
     int init_derived() override
     {
         if constexpr (P::NDER > 0) {

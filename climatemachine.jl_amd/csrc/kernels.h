@@ -62,6 +62,7 @@ struct PassArgs {
     int direction;     // direction of this pass (dg.direction or dg.diffusion_direction)
     int model_dir;     // dg.direction handed to the pointwise fluxes
     int nf_first;
+    HaloDev h;         // ghost exchange without pack / unpack launches (cmdg_common.h)
 };
 
 struct FacePt {
@@ -540,6 +541,7 @@ __global__ void __launch_bounds__((TendencyShape<P, NQ, NQV>::NT), CMDG_TEND_MIN
                             : a.aux[fp.vidM + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * e)];
 #pragma unroll
             for (int s = 0; s < NGF; ++s) gfM[s] = gfP[s] = 0.0;
+            const int gslot = ghost_slot<Np>(a.h, fp.eP, fp.vidP);
             if (use_gf) {
                 if constexpr (STAGE_M) {
 #pragma unroll
@@ -547,22 +549,20 @@ __global__ void __launch_bounds__((TendencyShape<P, NQ, NQV>::NT), CMDG_TEND_MIN
                 } else {
                     load_state<NGF, Np>(gfM, a.gf, fp.vidM, e);
                 }
-                load_state<NGF, Np>(gfP, a.gf, fp.vidP, fp.eP);
+                load_plus<NGF, Np, NGF>(gfP, a.gf, a.h.recvGF, gslot, fp.vidP, fp.eP);
             }
 #pragma unroll
             for (int s = 0; s < NHYP; ++s)
                 hypM[s] = STAGE_M ? sM[(NFA + NGFS + s) * NSURF + sidx]
                                   : a.hypgrad[fp.vidM + (int64_t)Np * (s + (int64_t)NHG * e)];
-            load_state<NS, Np>(QPn, a.Q, fp.vidP, fp.eP);
+            load_plus<NS, Np, NS>(QPn, a.Q, a.h.recvQ, gslot, fp.vidP, fp.eP);
 #pragma unroll
             for (int s = 0; s < NAUX; ++s) auxPn[s] = 0;
 #pragma unroll
             for (int s = 0; s < NFA; ++s)
                 auxPn[P::face_aux(s)] =
                     a.aux[fp.vidP + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * fp.eP)];
-#pragma unroll
-            for (int s = 0; s < NHYP; ++s)
-                hypP[s] = a.hypgrad[fp.vidP + (int64_t)Np * (s + (int64_t)NHG * fp.eP)];
+            load_plus<NHG, Np, NHYP>(hypP, a.hypgrad, a.h.recvHG, gslot, fp.vidP, fp.eP);
 #pragma unroll
             for (int s = 0; s < NS; ++s) QPd[s] = QPn[s];
 #pragma unroll
@@ -642,6 +642,12 @@ __global__ void __launch_bounds__((TendencyShape<P, NQ, NQV>::NT), CMDG_TEND_MIN
                 a.tendency[o] = T;
             }
         }
+    }
+    if constexpr (LSRK) {  // the updated state of the nodes of vmapsend, straight to the send buffer
+        if (live)
+            send_nodes<NS, NS>(a.h, 0, e, tid, EPB == 1 ? (int)SH::NT : (int)SH::NTE, [&](int s, int n) {
+                return sQ[s * Np + n] + a.rkb_dt * sT[s * Np + n];
+            });
     }
 }
 
@@ -877,7 +883,8 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LA
             if (fp.bctag == 0) {  // CentralNumericalFluxGradient  NumericalFluxes.jl:67-83
                 // the plus side is read inside the branch that uses it: of the neighbour's
                 // auxiliary columns only those the law's gradient argument touches are gathered
-                load_state<NS, Np>(QP, a.Q, fp.vidP, fp.eP);
+                load_plus<NS, Np, NS>(QP, a.Q, a.h.recvQ, ghost_slot<Np>(a.h, fp.eP, fp.vidP), fp.vidP,
+                                      fp.eP);
                 load_state<NAUX, Np>(auxP, a.aux, fp.vidP, fp.eP);
                 P::gradient_argument(a.prm, GP, QP, auxP, a.t);
 #pragma unroll
@@ -946,6 +953,11 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LA
         for (int s = 0; s < NHG; ++s)
             a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)] = sA[(NGF + s) * Np + tid];
     }
+    if constexpr (NGF > 0)
+        send_nodes<P::NGF, NGF>(a.h, 0, e, tid, (int)blockDim.x, [&](int s, int n) { return sA[s * Np + n]; });
+    if constexpr (NHG > 0)
+        send_nodes<NHG, NHG>(a.h, 1, e, tid, (int)blockDim.x,
+                             [&](int s, int n) { return sA[(NGF + s) * Np + n]; });
 }
 
 // ---------------------------------------------------------------------------------
@@ -1035,10 +1047,9 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT)) k_divgrad(const PassArgs
             Vec<NHG> gM, gP;
             const int sidx = surf_index<NQ, NQV>(fp.vidM);
 #pragma unroll
-            for (int q = 0; q < NHG; ++q) {
-                gM[q] = sM[q * NSURF + sidx];
-                gP[q] = a.hypgrad[fp.vidP + (int64_t)Np * (q + (int64_t)NHG * fp.eP)];
-            }
+            for (int q = 0; q < NHG; ++q) gM[q] = sM[q * NSURF + sidx];
+            load_plus<NHG, Np, NHG>(gP, a.hypgrad, a.h.recvHG, ghost_slot<Np>(a.h, fp.eP, fp.vidP),
+                                    fp.vidP, fp.eP);
             if (fp.bctag != 0) {  // numerical_boundary_flux_divergence!  :732-763
                 Vec<NAUX> auxM, auxP;
                 load_state<NAUX, Np>(auxM, a.aux, fp.vidM, e);
@@ -1071,6 +1082,9 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT)) k_divgrad(const PassArgs
         for (int s = 0; s < NGL; ++s)
             a.hypdiv[tid + (int64_t)Np * (s + (int64_t)NHYP * e)] = sA[s * Np + tid];
     }
+    // (the NGL columns this pass writes are all the next one reads of Qhypervisc_div)
+    if constexpr (NGL > 0)
+        send_nodes<NGL, NGL>(a.h, 0, e, tid, (int)blockDim.x, [&](int s, int n) { return sA[s * Np + n]; });
 }
 
 // ---------------------------------------------------------------------------------
@@ -1165,13 +1179,12 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_LAP_MINW) k_gradlap
             Vec<NGL> lapM, lapP;
             load_state<NS, Np>(QM, a.Q, fp.vidM, e);
             load_state<NAUX, Np>(auxM, a.aux, fp.vidM, e);
-            load_state<NS, Np>(QP, a.Q, fp.vidP, fp.eP);
+            const int gslot = ghost_slot<Np>(a.h, fp.eP, fp.vidP);
+            load_plus<NS, Np, NS>(QP, a.Q, a.h.recvQ, gslot, fp.vidP, fp.eP);
             load_state<NAUX, Np>(auxP, a.aux, fp.vidP, fp.eP);
 #pragma unroll
-            for (int s = 0; s < NGL; ++s) {
-                lapM[s] = sL[s * Np + fp.vidM];
-                lapP[s] = a.hypdiv[fp.vidP + (int64_t)Np * (s + (int64_t)NHYP * fp.eP)];
-            }
+            for (int s = 0; s < NGL; ++s) lapM[s] = sL[s * Np + fp.vidM];
+            load_plus<NHYP, Np, NGL, NGL>(lapP, a.hypdiv, a.h.recvHD, gslot, fp.vidP, fp.eP);
             if (fp.bctag != 0)  // numerical_boundary_flux_higher_order!  :792-832
                 P::boundary_state_higher_order(a.prm, fp.bctag, QP, auxP, lapP, fp.n, QM, auxM,
                                                lapM, a.t);
@@ -1203,6 +1216,8 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_LAP_MINW) k_gradlap
         for (int s = 0; s < NHYP; ++s)
             a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)] = sA[s * Np + tid];
     }
+    if constexpr (NHYP > 0)
+        send_nodes<NHG, NHYP>(a.h, 0, e, tid, (int)blockDim.x, [&](int s, int n) { return sA[s * Np + n]; });
 }
 
 // ---------------------------------------------------------------------------------
@@ -1252,9 +1267,11 @@ __global__ void k_init_derived(typename P::Params prm, const double *aux, double
 
 // ---------------------------------------------------------------------------------
 // kernel_fillsendbuf! / kernel_transferrecvbuf!  MPIStateArrays.jl:837-871
+// (nvar = columns per position of the packed buffer = the leading columns of the ncol-column array;
+// the reference packs whole arrays, nvar == ncol)
 static __global__ void k_fillsendbuf(double *__restrict__ sendbuf, const double *__restrict__ buf,
                               const int64_t *__restrict__ vmapsend, int64_t nvmap, int Np,
-                              int nvar)
+                              int nvar, int ncol)
 {
     const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= nvmap * nvar) return;
@@ -1262,11 +1279,11 @@ static __global__ void k_fillsendbuf(double *__restrict__ sendbuf, const double 
     const int s = (int)(I % nvar);
     const int64_t id = vmapsend[i] - 1;
     const int64_t e = id / Np, n = id % Np;
-    sendbuf[s + (int64_t)nvar * i] = buf[n + (int64_t)Np * (s + (int64_t)nvar * e)];
+    sendbuf[s + (int64_t)nvar * i] = buf[n + (int64_t)Np * (s + (int64_t)ncol * e)];
 }
 static __global__ void k_transferrecvbuf(double *__restrict__ buf, const double *__restrict__ recvbuf,
                                   const int64_t *__restrict__ vmaprecv, int64_t nvmap, int Np,
-                                  int nvar)
+                                  int nvar, int ncol)
 {
     const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= nvmap * nvar) return;
@@ -1274,7 +1291,7 @@ static __global__ void k_transferrecvbuf(double *__restrict__ buf, const double 
     const int s = (int)(I % nvar);
     const int64_t id = vmaprecv[i] - 1;
     const int64_t e = id / Np, n = id % Np;
-    buf[n + (int64_t)Np * (s + (int64_t)nvar * e)] = recvbuf[s + (int64_t)nvar * i];
+    buf[n + (int64_t)Np * (s + (int64_t)ncol * e)] = recvbuf[s + (int64_t)nvar * i];
 }
 
 // ---------------------------------------------------------------------------------

@@ -128,8 +128,18 @@ class DGModel:
     def set_option(self, option, value):
         """``cmdg_set_option``: ``_lib.OPT_KEEP_GRADFLUX`` = refresh ``state_gradient_flux`` in
         every evaluation even when the law's fluxes never read it (zero viscosity);
-        ``_lib.OPT_STACK_HEIGHT`` = elements per vertical stack (launch order only)."""
+        ``_lib.OPT_STACK_HEIGHT`` = elements per vertical stack (launch order only);
+        ``_lib.OPT_REFERENCE_HALO`` = pack / unpack kernels around every ghost exchange and ghost
+        elements refreshed, as the reference does (default: exterior launches write the send
+        buffers, face kernels read the receive buffers)."""
         _lib.check(self.L.cmdg_set_option(self.handle, int(option), int(value)), self.handle)
+
+    def query(self, item):
+        """``cmdg_query``: what the handle's kernels do (``_lib.CMDG_Q`` names, e.g.
+        ``"GRADFLUX_LIVE"``, ``"DIRECT_SEND"``)."""
+        out = C.c_int64()
+        _lib.check(self.L.cmdg_query(self.handle, _lib.CMDG_Q[item], C.byref(out)), self.handle)
+        return int(out.value)
 
     def close(self):
         if getattr(self, "handle", None):

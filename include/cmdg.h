@@ -158,9 +158,43 @@ int cmdg_synchronize(cmdg_handle h);
  *   topology (length(topology.stacksize); elements of a stack are contiguous, e = ev + (eh - 1) nv).
  *   Results do not depend on it.  With tall stacks (more than 16 elements) the engine walks its
  *   element lists in tiles of 32 columns x 4 levels instead of column by column, so that the
- *   elements in flight on one XCD are horizontal neighbours whose face gathers meet in its L2. */
-enum { CMDG_OPT_KEEP_GRADFLUX = 1, CMDG_OPT_STACK_HEIGHT = 2 };
+ *   elements in flight on one XCD are horizontal neighbours whose face gathers meet in its L2.
+ * CMDG_OPT_REFERENCE_HALO (default 0): handles with neighbours.  By default an evaluation launches
+ *   no pack or unpack kernel: the exterior launch of every pass writes the nodes of vmapsend of
+ *   what it produces straight into the send buffer, and -- unless the law's nodal
+ *   update_auxiliary_state! or the hooks read the ghost ELEMENTS -- the face kernels read the plus
+ *   side of ghost neighbours from the receive buffers, so the ghost elements of Q, of
+ *   state_gradient_flux and of the hyperdiffusion arrays are NOT refreshed.  Results are
+ *   bit-identical.  1 restores begin/end_ghost_exchange! as the reference runs them
+ *   (kernel_fillsendbuf! / kernel_transferrecvbuf! around every exchange, MPIStateArrays.jl:411-483),
+ *   for callers that read ghost elements after an evaluation.  cmdg_halo_begin/end always do.
+ * CMDG_OPT_HALO_PIPELINE (default 1): handles whose exchanges run direct both ways launch the
+ *   exterior element list of every pass on the halo stream, between the exchange it waits for
+ *   and the exchange it feeds (a chain without event hops), and the interior list on the compute
+ *   stream one pass behind or ahead (the passes of a step form two loosely coupled pipelines).
+ *   0: the reference's order on one compute stream (interior launch, wait, exterior launch).
+ *   Results do not depend on it. */
+enum {
+    CMDG_OPT_KEEP_GRADFLUX = 1, CMDG_OPT_STACK_HEIGHT = 2, CMDG_OPT_REFERENCE_HALO = 3,
+    CMDG_OPT_HALO_PIPELINE = 4
+};
 int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value);
+
+/* What the handle's kernels actually do, for byte accounting and tests (no reference counterpart):
+ *   GRADFLUX_LIVE         is state_gradient_flux formed by an evaluation (see CMDG_OPT_KEEP_GRADFLUX)
+ *   LAW_NEEDS_GRADFLUX    does the tendency pass read it
+ *   NDERIVED              columns of handle-owned time-invariant per-node fields the source reads
+ *   NUPDATED_AUX          auxiliary columns the law's nodal update_auxiliary_state! rewrites (0: none)
+ *   FUSED_UPDATE_AUX      is that refresh fused into the gradient pass
+ *   DIRECT_SEND / _RECV   is the ghost exchange running without pack / unpack launches
+ *   TENDENCY_ELEMS_PER_GROUP  elements per work-group of the tendency pass */
+enum {
+    CMDG_Q_GRADFLUX_LIVE = 1, CMDG_Q_LAW_NEEDS_GRADFLUX = 2, CMDG_Q_NDERIVED = 3,
+    CMDG_Q_NUPDATED_AUX = 4, CMDG_Q_FUSED_UPDATE_AUX = 5, CMDG_Q_DIRECT_SEND = 6,
+    CMDG_Q_DIRECT_RECV = 7, CMDG_Q_TENDENCY_ELEMS_PER_GROUP = 8,
+    CMDG_Q_HALO_PIPELINE = 9 /* are the two pipelines of CMDG_OPT_HALO_PIPELINE in use */
+};
+int cmdg_query(cmdg_handle h, int32_t what, int64_t *out);
 
 /* ---- halo (MPIStateArrays.jl:411-514, 837-871) -------------------------------- */
 /* begin_ghost_exchange!: pack face nodes of `array` (Np, nstate, nelem) and post the

@@ -33,6 +33,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--nvert", type=int, default=8)
     ap.add_argument("--nhorz", type=int, default=0)
+    ap.add_argument("--reference-halo", action="store_true",
+                    help="pack / unpack kernels around every exchange (CMDG_OPT_REFERENCE_HALO)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="interior and exterior launches on one stream (CMDG_OPT_HALO_PIPELINE = 0)")
     args = ap.parse_args()
     # face-connected ghosts: what a neighbour sends is what it receives (the vertex-connected
     # default of the stacked topologies lists a few hundred extra nodes on one side only)
@@ -55,6 +59,11 @@ def main():
     grid.nabrtorank = [0] * nn
     dg = cm.dgmodel.DGModel(law, grid, direction=direction[0], diffusion_direction=direction[1])
     dg.comm_init_rccl(cm.dgmodel.rccl_unique_id(), 0, 1)
+    if args.reference_halo:
+        dg.set_option(cm._lib.OPT_REFERENCE_HALO, 1)
+    if args.no_pipeline:
+        dg.set_option(cm._lib.OPT_HALO_PIPELINE, 0)
+    modes = {k: dg.query(k) for k in ("DIRECT_SEND", "DIRECT_RECV", "HALO_PIPELINE")}
     Q = dg.init_ode_state(0.0)
     solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
     solver.dostep(Q, nsteps=5)
@@ -73,6 +82,7 @@ def main():
            "interior_elements": int(len(grid.interiorelems)), "exterior_elements": int(len(grid.exteriorelems)),
            "neighbours": real_nbrs, "send_nodes_per_neighbour": [int(s[1] - s[0] + 1) for s in send],
            "bytes_per_exchange_per_state_column": int(8 * len(grid.vmapsend)),
+           "exchange": modes,
            "ms_per_step": 1e3 * el / args.steps, "steps": args.steps, "kernels": {}}
     for k in ("GRADIENTS", "DIVGRAD", "GRADLAP", "TENDENCY", "PACK", "TRANSPORT", "UNPACK", "HALO_EXPOSED"):
         ms, n = dg.profile_get(k)
