@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """DG-RHS DOF-update throughput of the MI355X-native hot path.
 
-``python bench.py --gpus N --steps K --warmup W``; for N > 1 launch with
-``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N``.
+``python bench.py --gpus N --steps K --warmup W``.  For N > 1 the command starts its own N ranks
+(one child process per GPU, before this process touches the GPU) unless it finds itself already
+launched as a rank (``RANK`` in the environment, e.g. under ``python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N``).
 
 One "step" is one LSRK54 time step = 5 fused (gradient pass + tendency/update pass)
 evaluations of the DG right-hand side on the rank's elements.  ``value`` is the whole-job
@@ -132,7 +134,7 @@ def build_workload(cm, name, rank, size, ne, args, nhorz=None, nvert=None):
 
 
 def hs_nhorz(scaling, size):
-    if scaling == "strong":
+    if scaling in ("strong", "both"):
         return 30
     if scaling == "weak-small":
         return {1: 11, 2: 15, 3: 18, 4: 21, 5: 24, 6: 26, 7: 28, 8: 30}.get(
@@ -154,6 +156,49 @@ def algorithmic_bytes_per_node(law, kernel, Nq=5):
         return b * (ngl + ns + naux + 9 + nhyp) + F
     if kernel == "TENDENCY":   # + fused LSRK: dQ read/write, Q write
         return b * (ns + naux + ngf + nhyp + 11 + 2 * ns + ns) + F
+    raise KeyError(kernel)
+
+
+def kernel_info(dg, law, grid, direction):
+    """What the handle's instantiation reads and writes (cmdg_query), for needed_bytes_per_node."""
+    Nq, Nqv = grid.N[0] + 1, grid.N[-1] + 1
+    return {"ns": law.ns, "naux": law.naux, "ngf": law.ngradflux, "ngl": law.ngradlap,
+            "nhyp": law.nhyper, "Nq": Nq, "Nqv": Nqv,
+            "direction": int(direction[0]), "diffusion_direction": int(direction[1]),
+            "gf_live": bool(dg.query("GRADFLUX_LIVE")),
+            "law_gf": bool(dg.query("LAW_NEEDS_GRADFLUX")),
+            "nder": dg.query("NDERIVED"),
+            "nupd_fused": dg.query("NUPDATED_AUX") if dg.query("FUSED_UPDATE_AUX") else 0}
+
+
+def needed_bytes_per_node(info, kernel):
+    """HBM bytes per node one launch of the SHIPPED instantiation needs, every distinct array
+    element counted once (a face neighbour's value is some work-group's own volume node):
+    what the kernel reads and writes in csrc/kernels.h, not SURVEY's generic formula --
+    a law whose second-order flux never reads state_gradient_flux (zero viscosity) has those
+    columns neither formed nor read; a pass differentiating in one direction reads only that
+    direction's metric rows; the face tables are the digested ones (faceP int32 + faceG 4 doubles
+    = 36 B per face node instead of 56)."""
+    b = 8
+    Nq, Nqv = info["Nq"], info["Nqv"]
+    Np, nft = Nq * Nq * Nqv, 4 * Nq * Nqv + 2 * Nq * Nq
+    F = 36.0 * nft / Np
+
+    def metric_rows(d):          # rows of d xi / d x the pass reads: 3 per differentiated axis
+        return {0: 9, 1: 6, 2: 3}[d]
+    ns, naux, ngf, ngl, nhyp = info["ns"], info["naux"], info["ngf"], info["ngl"], info["nhyp"]
+    dd, dm = info["diffusion_direction"], info["direction"]
+    if kernel == "GRADIENTS":    # reads Q, aux, metric, MI (faces); writes the fused aux refresh,
+        #                          the gradient flux if anybody reads it, the hyperdiffusion gradients
+        return b * (ns + naux + metric_rows(dd) + 1 + info["nupd_fused"]
+                    + (ngf if info["gf_live"] else 0) + 3 * ngl) + F
+    if kernel == "DIVGRAD":      # reads the gradients, M, MI, metric; writes ngl Laplacians
+        return b * (3 * ngl + 2 + metric_rows(dd) + ngl) + F
+    if kernel == "GRADLAP":      # reads the Laplacians, Q, aux, metric, MI; writes nhyp columns
+        return b * (ngl + ns + naux + metric_rows(dd) + 1 + nhyp) + F
+    if kernel == "TENDENCY":     # + fused LSRK: dQ read and written, Q written
+        return b * (ns + naux + (ngf if info["law_gf"] else 0) + nhyp + 2 + metric_rows(dm)
+                    + info["nder"] + 3 * ns) + F
     raise KeyError(kernel)
 
 
@@ -268,65 +313,53 @@ def timed_run(cm, dg, law, grid, dt, steps, warmup, sync_all, distributed, dev):
     return Q, solver, el
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="heldsuarez", choices=["heldsuarez", "advdiff-brick", "risingbubble", "bomex"])
-    ap.add_argument("--ne", type=int, default=32, help="advdiff-brick: elements per side per rank")
-    ap.add_argument("--bomex-ne", type=int, default=16,
-                    help="bomex: ne x ne x 2 ne elements per rank (32: the 65 536 elements of configs[3])")
-    ap.add_argument("--bomex-order", type=int, default=6,
-                    help="bomex: polynomial order (6: configs[3]; 4 for kernel-shape comparisons)")
-    ap.add_argument("--nhorz", type=int, default=0, help="heldsuarez: elements per cube edge")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "weak-small"],
-                    help="heldsuarez: weak = 43 200 elements per GPU (n_horz 30/42/60/85 at "
-                         "1/2/4/8 GPUs), strong = the 6x30x30x8 sphere split over the GPUs, "
-                         "weak-small = ~5 400 elements per GPU (n_horz 11/15/21/30)")
-    ap.add_argument("--no-parity", action="store_true", help="skip the in-run GPU vs oracle check")
-    ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary n_horz = 11 measurement of the one-GPU default run")
-    ap.add_argument("--nvert", type=int, default=8, help="heldsuarez: vertical elements")
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline")
-    ap.add_argument("--filter", action="store_true",
-                    help="heldsuarez: exponential filter of the perturbations after every step "
-                         "(experiments/AtmosGCM/heldsuarez.jl:261-272); off for the headline "
-                         "metric, which is the RHS + LSRK path alone")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-events", action="store_true", help="time without per-kernel HIP events")
-    args = ap.parse_args()
+PMC_FILES = {("heldsuarez", 43200): "r03_heldsuarez_n30_pmc_hbm_per_launch.json",
+             ("risingbubble", 8000): "r03_risingbubble_8000_pmc_hbm_per_launch.json",
+             ("bomex", 8192): "r03_bomex_n6_8192_pmc_hbm_per_launch.json"}
 
+
+def kernel_source_digest():
+    """Digest of the kernel sources: a committed PMC profile is quoted only for the kernels it was
+    taken on (scripts/pmc_any.sh stores the digest next to the counters)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "climatemachine.jl_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".h", ".hip")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(workload, nreal, dom):
+    """HBM-side traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this
+    same command (scripts/pmc_any.sh; FETCH_SIZE and WRITE_SIZE in separate passes, KB units,
+    FETCH_SIZE doubled as the gfx950 guide prescribes and as profiles/r01_pmc_calibration_n30.json
+    confirms for this library's 8-byte-per-lane loads).  Returned only when the profile was taken
+    on the kernel sources of this tree."""
+    name = PMC_FILES.get((workload, nreal))
+    if not name:
+        return None, None
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    rec = json.load(open(path))
+    if rec.get("kernel_source_digest") != kernel_source_digest():
+        return None, "profiles/%s is stale (taken on other kernel sources)" % name
+    pm = rec.get("k_%s" % dom.lower())
+    if not (pm and "FETCH_SIZE" in pm and "WRITE_SIZE" in pm):
+        return None, None
+    return 1024.0 * (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]), "profiles/" + name
+
+
+def measure(cm, args, workload_args, rank, world, distributed, dev, with_halo):
+    """Builds one workload on this rank, runs the timed region and the event pass, and (rank 0)
+    returns the fields of the JSON line for it."""
     import torch
     import torch.distributed as dist
-    from cmdg_loader import cm
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
-    torch.cuda.set_device(local)
-    dev = "cuda:%d" % local
-    # launched by torch.distributed.run (even with one rank): take the distributed path, so
-    # that a 1-rank launch rehearses process-group + RCCL set-up on a single-GPU box
-    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL prints a version banner on stdout at NCCL_DEBUG=VERSION; stdout carries the one
-        # JSON line of the contract
-        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = "WARN"
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(dev))
-
-    parity = None
-    if rank == 0 and world == 1 and not args.no_parity and not args.no_cpu:
-        parity = parity_check(cm, args, dev)
-        log("[parity] %s" % json.dumps(parity))
     t0 = time.time()
-    law, grid, direction, dt, desc = build_workload(cm, args.workload, rank, world, args.ne, args)
+    law, grid, direction, dt, desc = build_workload(cm, args.workload, rank, world, args.ne,
+                                                    workload_args)
     log("[rank %d] mesh+grid: %d real + %d ghost elements in %.1f s" % (
         rank, grid.nreal, grid.nelem - grid.nreal, time.time() - t0))
     dg = cm.dgmodel.DGModel(law, grid, direction=direction[0],
@@ -382,7 +415,7 @@ def main():
     el_events = time.perf_counter() - t1
     dg.profile_enable(False)
     finite = bool(torch.isfinite(Q[:grid.nreal]).all().item())
-
+    out = None
     if rank == 0:
         dofs = total_elems * grid.Np * law.ns * 5 * args.steps
         kern = {}
@@ -390,124 +423,302 @@ def main():
             ms, n = dg.profile_get(k)
             if n:
                 kern[k] = (ms / n, n)
-        if not kern:
-            print(json.dumps({"ms_per_step": 1e3 * el / args.steps, "value": dofs / el}), flush=True)
-            return
+        out = {"value": dofs / el, "ms_per_step": 1e3 * el / args.steps, "config": desc,
+               "node_updates_per_s": dofs / el / law.ns, "state_finite": finite,
+               "elements_total": total_elems,
+               "kernels_ms": {k: {"avg_ms": v[0], "launches": v[1]} for k, v in kern.items()}}
         # partitioned runs: rank 0's ghost exchange as the event pass saw it -- the RCCL group of
         # each exchange on the halo stream, and the time the compute stream had nothing left to
-        # do but wait for it (zero when the exchange finished behind the interior kernels)
-        halo = None
-        if world > 1 or os.environ.get("BENCH_HALO_BLOCK"):
+        # do but wait for the exterior pipeline / an exchange (zero when hidden)
+        if with_halo:
             halo = {"rank": 0, "real_elements": int(grid.nreal),
                     "ghost_elements": int(grid.nelem - grid.nreal),
-                    "neighbours": [int(r) for r in grid.nabrtorank]}
+                    "interior_elements": int(len(grid.interiorelems)),
+                    "exterior_elements": int(len(grid.exteriorelems)),
+                    "neighbours": [int(r) for r in grid.nabrtorank],
+                    "send_nodes": int(len(grid.vmapsend)),
+                    "exchange": {k.lower(): dg.query(k) for k in
+                                 ("DIRECT_SEND", "DIRECT_RECV", "HALO_PIPELINE")}}
             for key, name in (("TRANSPORT", "rccl_group"), ("HALO_EXPOSED", "exposed")):
                 ms, n = dg.profile_get(key)
                 if n:
                     halo[name + "_avg_us"] = 1e3 * ms / n
                     halo[name + "_ms_per_step"] = ms / args.steps
                     halo["exchanges_per_step"] = n / args.steps
-        dom = max((k for k in kern if k in ("GRADIENTS", "DIVGRAD", "GRADLAP", "TENDENCY")),
-                  key=lambda k: kern[k][0] * kern[k][1])
-        avg_ms, nl = kern[dom]
-        elems_per_launch = grid.nreal * 5 * args.steps / nl   # interior/exterior launches split
-        bytes_per_launch = algorithmic_bytes_per_node(law, dom, grid.N[0] + 1) * grid.Np * elems_per_launch
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        # HBM-side traffic of the dominant kernel from the committed rocprofv3 --pmc passes of
-        # this same command (scripts/pmc_any.sh; FETCH_SIZE and WRITE_SIZE in separate passes, KB
-        # units, FETCH_SIZE doubled as the gfx950 guide prescribes and as
-        # profiles/r01_pmc_calibration_n30.json confirms for this library's 8-byte-per-lane
-        # loads); only quoted for the configuration it was measured on
-        traffic, traffic_src = None, None
-        pmc_files = {("heldsuarez", 43200): "r02_heldsuarez_n30_pmc_hbm_per_launch.json",
-                     ("heldsuarez", 5808): "r01_heldsuarez_n11_pmc_hbm_per_launch.json",
-                     ("risingbubble", 8000): "r02_risingbubble_8000_pmc_hbm_per_launch.json",
-                     ("bomex", 8192): "r02_bomex_n6_8192_pmc_hbm_per_launch.json"}
-        pmc_name = pmc_files.get((args.workload, grid.nreal))
-        if pmc_name and world == 1 and not args.filter:
-            pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
-            if os.path.exists(pmc_file):
-                pm = json.load(open(pmc_file)).get("k_%s" % dom.lower())
-                if pm and "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
-                    traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"])
-                    traffic_src = "profiles/" + pmc_name
-        out = {
-            "metric": "DG RHS DOF-updates/sec", "value": dofs / el, "unit": "DOF-updates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-            "scaling": "strong" if (args.workload == "heldsuarez" and args.scaling == "strong") else "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": desc,
-            "node_updates_per_s": dofs / el / law.ns,
-            "state_finite": finite,
-            "kernels_ms": {k: {"avg_ms": v[0], "launches": v[1]} for k, v in kern.items()},
-            "halo": halo,
-            "roofline": {"bound": "hbm", "kernel": "k_%s" % dom.lower(), "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "traffic_source": ("committed rocprofv3 --pmc profile of this command, not "
-                                            "measured in this run: " + traffic_src) if traffic_src else None,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "algorithmic_bytes_per_node": algorithmic_bytes_per_node(law, dom, grid.N[0] + 1),
-                         "avg_launch_ms": avg_ms,
-                         "timing": "HIP events on the launch stream, second pass of the same "
-                                   "%d steps (%.3f ms/step with events)" % (
-                                       args.steps, 1e3 * el_events / args.steps)},
-        }
-        # flops of the (N+1)-point derivative contractions alone (2 (N+1) per
-        # node, differentiated scalar and direction): gradient arguments, the two hyperdiffusion
-        # passes, the tendency.  Secondary figure: the path is HBM bound (< 1 flop/B), the
-        # contraction runs on fp64 VALU out of LDS, not on MFMA.
-        cf = 6 * (grid.N[0] + 1) * (law.ngrad + 2 * law.ngradlap + law.ns)
-        out["contraction"] = {
-            "flops_per_node_update": cf,
-            "achieved_TFLOPs": cf * (dofs / law.ns) / el / 1e12,
-            "unit": "fp64 VALU out of LDS (v_mul_f64 + v_add_f64, no contraction of a*b+c)",
-            # the shipped kernels issue no MFMA; measured on this chip (profiles/r02_*):
-            "mfma_util": 0.0,
-            "measured_fp64_peaks_TFLOPs": {"v_mfma_f64_16x16x4_f64": 47.7, "v_mfma_f64_4x4x4_4b_f64": 72.7,
-                                           "v_fma_f64": 64.8, "v_mul_f64+v_add_f64": 34.0},
-            "mfma_variant": "k_gradients with the contraction on v_mfma_f64_16x16x4_f64: +70 % time, "
-                            "5.1 % matrix-pipe busy (SQ_VALU_MFMA_BUSY_CYCLES); contraction removed "
-                            "altogether: -2.1 % per step",
-            "evidence": ["profiles/r02_fp64_peak.jsonl", "profiles/r02_ab_mfma_contraction.txt",
-                         "profiles/r02_mfma_variant_pmc_per_launch.json"]}
+            out["halo"] = halo
+        passes = [k for k in kern if k in ("GRADIENTS", "DIVGRAD", "GRADLAP", "TENDENCY")]
+        if passes:
+            info = kernel_info(dg, law, grid, direction)
+            dom = max(passes, key=lambda k: kern[k][0] * kern[k][1])
+            avg_ms, nl = kern[dom]
+            elems_per_launch = grid.nreal * 5 * args.steps / nl   # interior/exterior launches split
+            nodes = grid.Np * elems_per_launch
+            needed = needed_bytes_per_node(info, dom)
+            achieved = needed * nodes / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_src = (None, None)
+            if world == 1 and not args.filter:
+                traffic, traffic_src = committed_traffic(args.workload, grid.nreal, dom)
+            survey = algorithmic_bytes_per_node(law, dom, grid.N[0] + 1)
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_%s" % dom.lower(), "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "traffic_over_needed": (traffic / (needed * nodes)) if traffic else None,
+                "traffic_source": ("committed rocprofv3 --pmc profile of this command on these "
+                                   "kernel sources, not measured in this run: " + traffic_src)
+                if traffic else traffic_src,
+                "algorithmic_bytes_per_launch": needed * nodes,
+                "algorithmic_bytes_per_node": needed,
+                "bytes_model": "what the shipped instantiation reads and writes, each distinct "
+                               "array element once (bench.needed_bytes_per_node)",
+                "survey_formula_bytes_per_node": survey,
+                "frac_on_survey_formula": survey * nodes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "avg_launch_ms": avg_ms,
+                "per_kernel": {k: {"needed_bytes_per_node": needed_bytes_per_node(info, k),
+                                   "frac": needed_bytes_per_node(info, k) * grid.Np * grid.nreal * 5
+                                   * args.steps / kern[k][1] / (kern[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                               for k in passes},
+                "timing": "HIP events on the launch stream, second pass of the same "
+                          "%d steps (%.3f ms/step with events)" % (
+                              args.steps, 1e3 * el_events / args.steps)}
+            # flops of the (N+1)-point derivative contractions alone (2 (N+1) per
+            # node, differentiated scalar and direction): gradient arguments, the two hyperdiffusion
+            # passes, the tendency.  Secondary figure: the path is HBM bound (< 1 flop/B), the
+            # contraction runs on fp64 VALU out of LDS, not on MFMA.
+            cf = 6 * (grid.N[0] + 1) * (law.ngrad + 2 * law.ngradlap + law.ns)
+            out["contraction"] = {
+                "flops_per_node_update": cf,
+                "achieved_TFLOPs": cf * (dofs / law.ns) / el / 1e12,
+                "unit": "fp64 VALU out of LDS (v_mul_f64 + v_add_f64, no contraction of a*b+c)",
+                # the shipped kernels issue no MFMA; measured on this chip (profiles/r02_*):
+                "mfma_util": 0.0,
+                "measured_fp64_peaks_TFLOPs": {"v_mfma_f64_16x16x4_f64": 47.7, "v_mfma_f64_4x4x4_4b_f64": 72.7,
+                                               "v_fma_f64": 64.8, "v_mul_f64+v_add_f64": 34.0},
+                "mfma_variant": "k_gradients with the contraction on v_mfma_f64_16x16x4_f64: +70 % time, "
+                                "5.1 % matrix-pipe busy (SQ_VALU_MFMA_BUSY_CYCLES); contraction removed "
+                                "altogether: -2.1 % per step",
+                "evidence": ["profiles/r02_fp64_peak.jsonl", "profiles/r02_ab_mfma_contraction.txt",
+                             "profiles/r02_mfma_variant_pmc_per_launch.json"]}
         if "FILTER" in kern:
             # Q read + written (5 fields each) and the two reference-state columns
             fb = 8 * (2 * law.ns + 2) * grid.Np * grid.nreal
             out["filter_kernel"] = {"avg_launch_ms": kern["FILTER"][0],
                                     "algorithmic_bytes_per_node": 8 * (2 * law.ns + 2),
                                     "achieved_GBs": fb / (kern["FILTER"][0] * 1e-3) / 1e9}
-        if parity is not None:
-            out["parity"] = parity
-        if (world == 1 and args.workload == "heldsuarez" and not args.nhorz and not args.filter
-                and args.scaling == "weak" and not args.no_secondary):
-            # the round-1 headline size (SURVEY section 8(d)'s weak-scaling base of ~5 400 elements
-            # per GPU), so that numbers of that family stay comparable
-            law2, grid2, dir2, dt2, desc2 = build_workload(cm, "heldsuarez", 0, 1, 0, args, nhorz=11)
-            dg2 = cm.dgmodel.DGModel(law2, grid2, direction=dir2[0], diffusion_direction=dir2[1],
-                                     device=dev)
-
-            def sync2():
-                dg2.synchronize()
-                torch.cuda.synchronize()
-            _, _, el2 = timed_run(cm, dg2, law2, grid2, dt2, args.steps, args.warmup, sync2, False, dev)
-            dg2.close()
-            out["secondary"] = {"workload": desc2["workload"], "elements": grid2.nreal,
-                                "value": grid2.nreal * grid2.Np * law2.ns * 5 * args.steps / el2,
-                                "ms_per_step": 1e3 * el2 / args.steps}
-        if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cm, law, grid, direction, dt, args.cpu_budget, args)
-        print(json.dumps(out), flush=True)
-        if not finite:
-            raise SystemExit("bench.py: the state is not finite after the timed steps")
+        out["_cpu_inputs"] = (law, grid, direction, dt)
     if step_filter is not None:
         dg.set_filters()
         step_filter.close()
     dg.close()
+    return out
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """``--gpus N`` without a launcher: start one child process per GPU with the environment
+    torch.distributed.run would give it.  This process has not touched the GPU (no torch import,
+    no HIP call) and never does; rank 0's stdout -- the one JSON line -- is relayed, everything
+    else goes to stderr; the exit code is non-zero if any rank's is."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT") or free_port())
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr))
+    deadline = time.time() + 3600
+    try:
+        line = procs[0].communicate(timeout=3600)[0].decode()
+    except subprocess.TimeoutExpired:
+        line = ""
+    codes = []
+    for p_ in procs:
+        try:
+            codes.append(p_.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            codes.append(-9)
+    if any(codes):
+        for p_ in procs:          # exactly the children started above
+            if p_.poll() is None:
+                p_.kill()
+        log("bench.py: rank exit codes %s" % codes)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        raise SystemExit(next(c for c in codes if c) or 1)
+    sys.stdout.write(line)
+    sys.stdout.flush()
+
+
+def parse_args(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="heldsuarez",
+                    choices=["heldsuarez", "advdiff-brick", "risingbubble", "bomex",
+                             "ocean-split-explicit"])
+    ap.add_argument("--ne", type=int, default=32, help="advdiff-brick: elements per side per rank")
+    ap.add_argument("--bomex-ne", type=int, default=16,
+                    help="bomex: ne x ne x 2 ne elements per rank (32: the 65 536 elements of configs[3])")
+    ap.add_argument("--bomex-order", type=int, default=6,
+                    help="bomex: polynomial order (6: configs[3]; 4 for kernel-shape comparisons)")
+    ap.add_argument("--nhorz", type=int, default=0, help="heldsuarez: elements per cube edge")
+    ap.add_argument("--scaling", default="both", choices=["both", "weak", "strong", "weak-small"],
+                    help="heldsuarez on N > 1 GPUs: strong = the 6x30x30x8 sphere of BASELINE "
+                         "configs[2] split over the GPUs, weak = 43 200 elements per GPU (n_horz "
+                         "30/42/60/85 at 1/2/4/8 GPUs), weak-small = ~5 400 elements per GPU (n_horz "
+                         "11/15/21/30); both (default) = strong as the headline and weak under "
+                         "'secondary' of the same line.  On one GPU all but weak-small are the "
+                         "same 43 200-element sphere")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run GPU vs oracle check")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurement (one GPU: n_horz = 11; N GPUs: the weak family)")
+    ap.add_argument("--no-n1-reference", action="store_true",
+                    help="N > 1: skip rank 0's one-GPU run of the 43 200-element sphere that "
+                         "efficiency_vs_n1 is computed against")
+    ap.add_argument("--nvert", type=int, default=8, help="heldsuarez: vertical elements")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline")
+    ap.add_argument("--filter", action="store_true",
+                    help="heldsuarez: exponential filter of the perturbations after every step "
+                         "(experiments/AtmosGCM/heldsuarez.jl:261-272); off for the headline "
+                         "metric, which is the RHS + LSRK path alone")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="time without per-kernel HIP events")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the ranks as usual, but each only prints its launch environment "
+                         "(no torch, no GPU): checks the launcher itself")
+    return ap.parse_args(argv)
+
+
+def with_scaling(args, scaling):
+    import copy
+    a = copy.copy(args)
+    a.scaling = scaling
+    return a
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        return launch_ranks(args, argv)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_launch:
+        rec = {"rank": rank, "world": world, "local_rank": local,
+               "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
+               "gpus": args.gpus, "torch_imported": "torch" in sys.modules}
+        if rank == 0:
+            print(json.dumps({"dry_launch": rec}), flush=True)
+        else:
+            log("[dry-launch] %s" % json.dumps(rec))
+        if os.environ.get("BENCH_DRY_FAIL_RANK") == str(rank):
+            raise SystemExit(3)
+        return
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.workload == "ocean-split-explicit":
+        return main_ocean(args, rank, world, local)
+
+    import torch
+    import torch.distributed as dist
+    from cmdg_loader import cm
+
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+    # launched as a rank (even a single one): take the distributed path, so that a 1-rank
+    # launch rehearses process-group + RCCL set-up on a single-GPU box
+    distributed = launched
+    gloo = None
     if distributed:
-        dist.barrier()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL prints a version banner on stdout at NCCL_DEBUG=VERSION; stdout carries the one
+        # JSON line of the contract
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device(dev))
+        gloo = dist.new_group(backend="gloo")    # long waits without a spinning RCCL kernel
+
+    parity = None
+    if rank == 0 and world == 1 and not args.no_parity and not args.no_cpu:
+        parity = parity_check(cm, args, dev)
+        log("[parity] %s" % json.dumps(parity))
+
+    hs = args.workload == "heldsuarez"
+    both = hs and world > 1 and args.scaling == "both" and not args.nhorz
+    head_scaling = "strong" if (hs and args.scaling in ("both", "strong")) else (
+        args.scaling if hs else "weak")
+    main_args = with_scaling(args, "strong" if head_scaling == "strong" else args.scaling)
+    res = measure(cm, args, main_args, rank, world, distributed, dev,
+                  with_halo=world > 1 or bool(os.environ.get("BENCH_HALO_BLOCK")))
+    sec = None
+    if both and not args.no_secondary:
+        sec = measure(cm, args, with_scaling(args, "weak"), rank, world, distributed, dev, with_halo=True)
+    n1 = None
+    if world > 1 and hs and not args.no_n1_reference and not args.nhorz:
+        # the one-GPU value both families are scaled against, measured by rank 0 alone on its GPU
+        # while the others wait (CPU barrier): the 43 200-element sphere of BASELINE configs[2]
+        if rank == 0:
+            n1 = measure(cm, args, with_scaling(args, "strong"), 0, 1, False, dev, with_halo=False)
+        dist.barrier(group=gloo)
+
+    if rank == 0:
+        law, grid, direction, dt = res.pop("_cpu_inputs")
+        out = {"metric": "DG RHS DOF-updates/sec", "value": res.pop("value"), "unit": "DOF-updates/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
+               "scaling": "strong" if head_scaling == "strong" else "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+        out.update(res)
+        if parity is not None:
+            out["parity"] = parity
+        if n1 is not None:
+            n1.pop("_cpu_inputs")
+            out["n1_reference"] = {"value": n1["value"], "ms_per_step": n1["ms_per_step"],
+                                   "elements": n1["elements_total"],
+                                   "note": "rank 0 alone, same steps / warm-up, no neighbours"}
+            out["efficiency_vs_n1"] = out["value"] / (world * n1["value"])
+        if sec is not None:
+            sec.pop("_cpu_inputs")
+            s2 = {"scaling": "weak", "value": sec["value"], "ms_per_step": sec["ms_per_step"],
+                  "workload": sec["config"]["workload"], "elements": sec["elements_total"],
+                  "halo": sec.get("halo"), "kernels_ms": sec["kernels_ms"],
+                  "roofline": sec.get("roofline")}
+            if n1 is not None:
+                s2["efficiency_vs_n1"] = sec["value"] / (world * n1["value"])
+            out["secondary"] = s2
+        elif (world == 1 and hs and not args.nhorz and not args.filter
+                and args.scaling != "weak-small" and not args.no_secondary):
+            # the round-1 headline size (SURVEY section 8(d)'s weak-scaling base of ~5 400 elements
+            # per GPU), so that numbers of that family stay comparable
+            a2 = with_scaling(args, "weak-small")
+            r2 = measure(cm, args, a2, 0, 1, False, dev, with_halo=False)
+            out["secondary"] = {"workload": r2["config"]["workload"], "elements": r2["elements_total"],
+                                "value": r2["value"], "ms_per_step": r2["ms_per_step"]}
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cm, law, grid, direction, dt, args.cpu_budget, args)
+        print(json.dumps(out), flush=True)
+        if not out["state_finite"]:
+            raise SystemExit("bench.py: the state is not finite after the timed steps")
+    if distributed:
+        dist.barrier(group=gloo)
         dist.destroy_process_group()
+
+
+def main_ocean(args, rank, world, local):
+    raise SystemExit("ocean-split-explicit: not built yet")
 
 
 if __name__ == "__main__":

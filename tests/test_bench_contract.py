@@ -1,6 +1,10 @@
 """bench.py's bookkeeping, checked without a GPU: SURVEY section 8(d)'s per-node byte counts
-(the figures DESIGN.md section 3 tabulates) and the element counts of the weak-scaling family."""
+(the figures DESIGN.md section 3 tabulates), the bytes the shipped instantiations need (what
+``roofline.frac`` is computed from), the element counts of the scaling families, and the
+launcher that starts one rank per GPU."""
+import json
 import os
+import subprocess
 import sys
 import types
 
@@ -28,3 +32,75 @@ def test_weak_family_keeps_the_baseline_sphere_per_gpu():
     assert all(abs(v - 43200) / 43200 < 0.025 for v in per_gpu.values()), per_gpu
     assert bench.hs_nhorz("strong", 8) == 30
     assert 6 * bench.hs_nhorz("weak-small", 8) ** 2 * 8 / 8 == 5400
+
+
+def _hs_info(**kw):
+    info = {"ns": 5, "naux": 17, "ngf": 9, "ngl": 4, "nhyp": 12, "Nq": 5, "Nqv": 5,
+            "direction": 0, "diffusion_direction": 1, "gf_live": False, "law_gf": False,
+            "nder": 2, "nupd_fused": 2}
+    info.update(kw)
+    return info
+
+
+def test_needed_bytes_follow_the_instantiation():
+    """Held-Suarez has zero viscosity: the nine gradient-flux columns are neither formed by
+    k_gradients nor read by k_tendency<..., USE_GF = false>, so they are not counted; the face
+    tables are the digested 36 B per face node (43.2 B per node at N = 4), not 67."""
+    hs = _hs_info()
+    F = 36.0 * 150 / 125
+    assert abs(bench.needed_bytes_per_node(hs, "TENDENCY") - (8 * (5 + 17 + 12 + 2 + 9 + 2 + 15) + F)) < 1e-9
+    assert abs(bench.needed_bytes_per_node(hs, "GRADIENTS") - (8 * (5 + 17 + 6 + 1 + 2 + 12) + F)) < 1e-9
+    assert abs(bench.needed_bytes_per_node(hs, "DIVGRAD") - (8 * (12 + 2 + 6 + 4) + F)) < 1e-9
+    assert abs(bench.needed_bytes_per_node(hs, "GRADLAP") - (8 * (4 + 5 + 17 + 6 + 1 + 12) + F)) < 1e-9
+    # the needed bytes never exceed SURVEY's generic count for this law, and keeping the gradient
+    # flux alive (CMDG_OPT_KEEP_GRADFLUX, or a viscous law) puts the 72 B back
+    law = types.SimpleNamespace(ns=5, naux=17, ngradflux=9, ngradlap=4, nhyper=12)
+    for k in ("GRADIENTS", "GRADLAP", "TENDENCY"):
+        assert bench.needed_bytes_per_node(hs, k) < bench.algorithmic_bytes_per_node(law, k)
+    live = _hs_info(gf_live=True, law_gf=True)
+    assert bench.needed_bytes_per_node(live, "TENDENCY") - bench.needed_bytes_per_node(hs, "TENDENCY") == 72
+    assert bench.needed_bytes_per_node(live, "GRADIENTS") - bench.needed_bytes_per_node(hs, "GRADIENTS") == 72
+    # the frac of round 2's profile on these bytes: no kernel above 1 (k_gradients read 1.01 on
+    # the stale model), the headline kernel near 0.5
+    nodes = 43200 * 125
+    for k, us in (("TENDENCY", 709.8), ("GRADIENTS", 322.5)):
+        frac = bench.needed_bytes_per_node(hs, k) * nodes / (us * 1e-6) / 8e12
+        assert 0.3 < frac < 0.9, (k, frac)
+
+
+def test_strong_family_is_the_baseline_sphere():
+    assert bench.hs_nhorz("strong", 1) == bench.hs_nhorz("strong", 8) == 30
+    assert bench.hs_nhorz("both", 8) == 30
+
+
+def _bench(*argv, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(os.path.dirname(bench.__file__), "bench.py")]
+                          + list(argv), env=e, capture_output=True, text=True, timeout=120)
+
+
+def test_launcher_starts_one_rank_per_gpu_without_touching_the_gpu():
+    """``python bench.py --gpus 3`` with no RANK in the environment starts three children with
+    the environment torch.distributed.run would give them and relays rank 0's one line."""
+    r = _bench("--gpus", "3", "--dry-launch")
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1                                  # ONE JSON line on stdout
+    rec = json.loads(lines[0])["dry_launch"]
+    assert rec["rank"] == 0 and rec["world"] == 3 and rec["gpus"] == 3
+    assert rec["master"].startswith("127.0.0.1:") and not rec["torch_imported"]
+    others = [json.loads(ln.split("] ", 1)[1]) for ln in r.stderr.splitlines() if ln.startswith("[dry-launch]")]
+    assert sorted(o["rank"] for o in others) == [1, 2]
+    assert all(o["master"] == rec["master"] and o["local_rank"] == o["rank"] for o in others)
+
+
+def test_launcher_fails_when_a_rank_fails():
+    r = _bench("--gpus", "2", "--dry-launch", env={"BENCH_DRY_FAIL_RANK": "1"})
+    assert r.returncode == 3
+    # launched as a rank already (torch.distributed.run): no second generation of children
+    r = _bench("--gpus", "2", "--dry-launch", env={"RANK": "1", "WORLD_SIZE": "2", "LOCAL_RANK": "1",
+                                                   "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "1"})
+    assert r.returncode == 0 and r.stdout.strip() == "" and "[dry-launch]" in r.stderr
