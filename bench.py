@@ -168,6 +168,8 @@ def kernel_info(dg, law, grid, direction):
             "gf_live": bool(dg.query("GRADFLUX_LIVE")),
             "law_gf": bool(dg.query("LAW_NEEDS_GRADFLUX")),
             "nder": dg.query("NDERIVED"),
+            "q_read": [dg.query(("STATE_READ", p)) for p in range(4)],
+            "aux_read": [dg.query(("AUX_READ", p)) for p in range(4)],
             "nupd_fused": dg.query("NUPDATED_AUX") if dg.query("FUSED_UPDATE_AUX") else 0}
 
 
@@ -176,9 +178,12 @@ def needed_bytes_per_node(info, kernel):
     element counted once (a face neighbour's value is some work-group's own volume node):
     what the kernel reads and writes in csrc/kernels.h, not SURVEY's generic formula --
     a law whose second-order flux never reads state_gradient_flux (zero viscosity) has those
-    columns neither formed nor read; a pass differentiating in one direction reads only that
-    direction's metric rows; the face tables are the digested ones (faceP int32 + faceG 4 doubles
-    = 36 B per face node instead of 56)."""
+    columns neither formed nor read; of Q and the auxiliary state a pass reads the columns its
+    pointwise functions use (the law declares them: P::state_read / P::aux_read, e.g. 6 of the
+    dry atmosphere's 17 auxiliary columns in the tendency pass; every column for a law that does
+    not say); a pass differentiating in one direction reads only that direction's metric rows;
+    the face tables are the digested ones (faceP int32 + faceG 4 doubles = 36 B per face node
+    instead of 56)."""
     b = 8
     Nq, Nqv = info["Nq"], info["Nqv"]
     Np, nft = Nq * Nq * Nqv, 4 * Nq * Nqv + 2 * Nq * Nq
@@ -186,18 +191,20 @@ def needed_bytes_per_node(info, kernel):
 
     def metric_rows(d):          # rows of d xi / d x the pass reads: 3 per differentiated axis
         return {0: 9, 1: 6, 2: 3}[d]
-    ns, naux, ngf, ngl, nhyp = info["ns"], info["naux"], info["ngf"], info["ngl"], info["nhyp"]
+    ns, ngf, ngl, nhyp = info["ns"], info["ngf"], info["ngl"], info["nhyp"]
+    qr = info.get("q_read") or [ns] * 4
+    ar = info.get("aux_read") or [info["naux"]] * 4
     dd, dm = info["diffusion_direction"], info["direction"]
     if kernel == "GRADIENTS":    # reads Q, aux, metric, MI (faces); writes the fused aux refresh,
         #                          the gradient flux if anybody reads it, the hyperdiffusion gradients
-        return b * (ns + naux + metric_rows(dd) + 1 + info["nupd_fused"]
+        return b * (qr[0] + ar[0] + metric_rows(dd) + 1 + info["nupd_fused"]
                     + (ngf if info["gf_live"] else 0) + 3 * ngl) + F
     if kernel == "DIVGRAD":      # reads the gradients, M, MI, metric; writes ngl Laplacians
         return b * (3 * ngl + 2 + metric_rows(dd) + ngl) + F
     if kernel == "GRADLAP":      # reads the Laplacians, Q, aux, metric, MI; writes nhyp columns
-        return b * (ngl + ns + naux + metric_rows(dd) + 1 + nhyp) + F
+        return b * (ngl + qr[2] + ar[2] + metric_rows(dd) + 1 + nhyp) + F
     if kernel == "TENDENCY":     # + fused LSRK: dQ read and written, Q written
-        return b * (ns + naux + (ngf if info["law_gf"] else 0) + nhyp + 2 + metric_rows(dm)
+        return b * (qr[3] + ar[3] + (ngf if info["law_gf"] else 0) + nhyp + 2 + metric_rows(dm)
                     + info["nder"] + 3 * ns) + F
     raise KeyError(kernel)
 

@@ -1463,7 +1463,16 @@ int cmdg_query(cmdg_handle h, int32_t what, int64_t *out)
     case CMDG_Q_HALO_PIPELINE:
         *out = e->pipelined(e->communicate() && !(e->stacked && e->direction == DIR_VERTICAL)) && !e->has_hooks;
         return CMDG_OK;
-    default: return set_err(h, h->eng->fail(CMDG_ERR_INVALID, "cmdg_query: unknown item"));
+    default:
+        if (what >= CMDG_Q_STATE_READ && what < CMDG_Q_STATE_READ + 4) {
+            *out = e->law_state_read(what - CMDG_Q_STATE_READ);
+            return CMDG_OK;
+        }
+        if (what >= CMDG_Q_AUX_READ && what < CMDG_Q_AUX_READ + 4) {
+            *out = e->law_aux_read(what - CMDG_Q_AUX_READ);
+            return CMDG_OK;
+        }
+        return set_err(h, h->eng->fail(CMDG_ERR_INVALID, "cmdg_query: unknown item"));
     }
 }
 

@@ -142,6 +142,8 @@ struct EngineBase {
     virtual int law_nder() const = 0;
     virtual int law_nupd() const = 0;
     virtual int tendency_epb() const = 0;
+    virtual int law_state_read(int pass) const = 0;
+    virtual int law_aux_read(int pass) const = 0;
     virtual int init_derived() = 0;
     // mode 0: per-element minimum node distance, mode 1: per-element maximum Courant number
     virtual int launch_courant(int mode, int kind, const double *Q, double dt, double t, int dir,
@@ -380,17 +382,23 @@ struct EngineT : EngineBase {
         const dim3 grid((unsigned)SH::blocks(n)), block(SH::NT);
         PassArgs<P> args = make_args(c, elems, n, direction);
         args.h = halo_dev(exterior, c.lsrk ? slot[SLOT_Q].sendbuf : nullptr, nullptr);
+        const bool recv = args.h.ghostslot != nullptr && exterior;  // (interior elements have no ghost neighbour)
+        if (!recv) args.h.ghostslot = nullptr;
+#define CMDG_TEND(L, G)                                                                             \
+    do {                                                                                            \
+        if (recv)                                                                                   \
+            hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, L, G, true>), grid, block, 0, st, args);   \
+        else                                                                                        \
+            hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, L, G, false>), grid, block, 0, st, args);  \
+    } while (0)
         if (c.lsrk) {
-            if (gfl)
-                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, true, true>), grid, block, 0, st, args);
-            else
-                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, true, false>), grid, block, 0, st, args);
+            if (gfl) CMDG_TEND(true, true);
+            else CMDG_TEND(true, false);
         } else {
-            if (gfl)
-                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, false, true>), grid, block, 0, st, args);
-            else
-                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, false, false>), grid, block, 0, st, args);
+            if (gfl) CMDG_TEND(false, true);
+            else CMDG_TEND(false, false);
         }
+#undef CMDG_TEND
         prof_end(st);
     }
     void launch_update_aux(const RhsCtx &c, int64_t e0, int64_t e1) override
@@ -424,6 +432,8 @@ struct EngineT : EngineBase {
     int law_nder() const override { return P::HAS_SOURCE ? P::NDER : 0; }
     int law_nupd() const override { return P::HAS_UPDATE_AUX ? P::NUPD : 0; }
     int tendency_epb() const override { return TendencyShape<P, NQ_, NQV_>::EPB; }
+    int law_state_read(int pass) const override { return law_reads<P>::state(pass); }
+    int law_aux_read(int pass) const override { return law_reads<P>::aux(pass); }
     int init_derived() override
     {
         if constexpr (P::NDER > 0) {

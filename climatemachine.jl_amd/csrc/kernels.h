@@ -194,6 +194,19 @@ template <class P>
 struct node_cache_size<P, std::void_t<decltype(P::NCACHE)>> : std::integral_constant<int, P::NCACHE> {
 };
 
+// byte accounting: columns of Q / of the auxiliary state the volume code of a pass reads
+// (P::state_read, P::aux_read; every column for a law that does not say)
+template <class P, class = void>
+struct law_reads {
+    static constexpr int state(int) { return P::NS; }
+    static constexpr int aux(int) { return P::NAUX; }
+};
+template <class P>
+struct law_reads<P, std::void_t<decltype(P::aux_read(0))>> {
+    static constexpr int state(int pass) { return P::state_read(pass); }
+    static constexpr int aux(int pass) { return P::aux_read(pass); }
+};
+
 // laws that carry numerical_flux_first_order! methods of their own (P::LAW_NF)
 template <class P, class = void>
 struct has_law_nf : std::false_type {
@@ -334,7 +347,11 @@ struct TendencyShape {
 // ---------------------------------------------------------------------------------
 // Tendency pass: volume_tendency! (:64-548) + dgsem_interface_tendency! (:588-901),
 // optionally fused with the LSRK update! (LowStorageRungeKuttaMethod.jl:146-158).
-template <class P, int NQ, int NQV, bool LSRK, bool USE_GF>
+// RECV: the plus side of ghost neighbours comes from the receive buffers (exterior launches of a
+// handle whose exchanges are not unpacked).  A variant of its own: the second addressing mode
+// costs the Held-Suarez instantiation 24 VGPRs (128 -> 150, one wave per SIMD less), which the
+// interior launches and single-rank handles do not pay.
+template <class P, int NQ, int NQV, bool LSRK, bool USE_GF, bool RECV = false>
 __global__ void __launch_bounds__((TendencyShape<P, NQ, NQV>::NT), CMDG_TEND_MINW) k_tendency(const PassArgs<P> a)
 {
     using KD = KDims<NQ, NQV>;
@@ -541,7 +558,7 @@ __global__ void __launch_bounds__((TendencyShape<P, NQ, NQV>::NT), CMDG_TEND_MIN
                             : a.aux[fp.vidM + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * e)];
 #pragma unroll
             for (int s = 0; s < NGF; ++s) gfM[s] = gfP[s] = 0.0;
-            const int gslot = ghost_slot<Np>(a.h, fp.eP, fp.vidP);
+            const int gslot = RECV ? ghost_slot<Np>(a.h, fp.eP, fp.vidP) : -1;
             if (use_gf) {
                 if constexpr (STAGE_M) {
 #pragma unroll

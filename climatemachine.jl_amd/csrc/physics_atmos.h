@@ -63,6 +63,21 @@ struct DryAtmos {
     // sin / cos of the latitude (heldsuarez.jl:134,147-149 recomputes them every call; they
     // only depend on aux.coord, so they are evaluated once with the same libm calls)
     static constexpr int NDER = ORIENT ? 2 : 0;
+    // Byte accounting (cmdg_query, bench.py): columns of Q and of the auxiliary state the
+    // volume code of a pass actually reads -- load_state asks for all of them and the compiler
+    // drops the loads nobody uses.  pass: 0 gradients, 1 Laplacian, 2 gradient of Laplacian,
+    // 3 tendency.  Gradients: Phi through the internal energy (gradient argument, fused nodal
+    // refresh), grad Phi for the horizontal projection of u (DryBiharmonic) or N^2
+    // (SmagorinskyLilly).  Gradient of Laplacian: hyperdiffusion.Delta alone (nu_4), no state.
+    // Tendency: Phi, grad Phi (gravity, Held-Suarez drag), ref_state rho and p, turbulence.Delta.
+    __host__ __device__ static constexpr int state_read(int pass) { return pass == 1 || pass == 2 ? 0 : NS; }
+    __host__ __device__ static constexpr int aux_read(int pass)
+    {
+        return pass == 0 ? (ORIENT ? 1 + ((HYPER || SMAG) ? 3 : 0) : 0)
+               : pass == 1 ? 0
+               : pass == 2 ? (HYPER ? 1 : 0)
+                           : (ORIENT ? 4 : 0) + (REF ? 2 : 0) + (SMAG ? 1 : 0);
+    }
     __host__ __device__ static constexpr int hv_indexmap(int s) { return 4 + s; }
     // tau = (-2 nu) S and D_t = nu / Pr: with nu == 0 the gradient-flux state only multiplies zeros
     __host__ __device__ static bool needs_gradflux(const Params &m) { return SMAG || m.visc != 0; }

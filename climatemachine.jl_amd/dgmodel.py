@@ -136,9 +136,10 @@ class DGModel:
 
     def query(self, item):
         """``cmdg_query``: what the handle's kernels do (``_lib.CMDG_Q`` names, e.g.
-        ``"GRADFLUX_LIVE"``, ``"DIRECT_SEND"``)."""
+        ``"GRADFLUX_LIVE"``, ``"DIRECT_SEND"``; ``("AUX_READ", p)`` for pass ``p``)."""
         out = C.c_int64()
-        _lib.check(self.L.cmdg_query(self.handle, _lib.CMDG_Q[item], C.byref(out)), self.handle)
+        what = _lib.CMDG_Q[item[0]] + int(item[1]) if isinstance(item, tuple) else _lib.CMDG_Q[item]
+        _lib.check(self.L.cmdg_query(self.handle, what, C.byref(out)), self.handle)
         return int(out.value)
 
     def close(self):

@@ -187,12 +187,16 @@ int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value);
  *   NUPDATED_AUX          auxiliary columns the law's nodal update_auxiliary_state! rewrites (0: none)
  *   FUSED_UPDATE_AUX      is that refresh fused into the gradient pass
  *   DIRECT_SEND / _RECV   is the ghost exchange running without pack / unpack launches
- *   TENDENCY_ELEMS_PER_GROUP  elements per work-group of the tendency pass */
+ *   TENDENCY_ELEMS_PER_GROUP  elements per work-group of the tendency pass
+ *   STATE_READ + p, AUX_READ + p   columns of Q / of state_auxiliary the volume code of pass p
+ *                         reads (p = 0 gradients, 1 Laplacian, 2 gradient of Laplacian, 3 tendency);
+ *                         every column for a law that does not declare less */
 enum {
     CMDG_Q_GRADFLUX_LIVE = 1, CMDG_Q_LAW_NEEDS_GRADFLUX = 2, CMDG_Q_NDERIVED = 3,
     CMDG_Q_NUPDATED_AUX = 4, CMDG_Q_FUSED_UPDATE_AUX = 5, CMDG_Q_DIRECT_SEND = 6,
     CMDG_Q_DIRECT_RECV = 7, CMDG_Q_TENDENCY_ELEMS_PER_GROUP = 8,
-    CMDG_Q_HALO_PIPELINE = 9 /* are the two pipelines of CMDG_OPT_HALO_PIPELINE in use */
+    CMDG_Q_HALO_PIPELINE = 9, /* are the two pipelines of CMDG_OPT_HALO_PIPELINE in use */
+    CMDG_Q_STATE_READ = 16, CMDG_Q_AUX_READ = 20
 };
 int cmdg_query(cmdg_handle h, int32_t what, int64_t *out);
 
