@@ -578,6 +578,8 @@ def parse_args(argv):
                     help="bomex: ne x ne x 2 ne elements per rank (32: the 65 536 elements of configs[3])")
     ap.add_argument("--bomex-order", type=int, default=6,
                     help="bomex: polynomial order (6: configs[3]; 4 for kernel-shape comparisons)")
+    ap.add_argument("--ocean-nx", type=int, default=48, help="ocean-split-explicit: horizontal elements per side")
+    ap.add_argument("--ocean-nz", type=int, default=16, help="ocean-split-explicit: vertical elements")
     ap.add_argument("--nhorz", type=int, default=0, help="heldsuarez: elements per cube edge")
     ap.add_argument("--scaling", default="both", choices=["both", "weak", "strong", "weak-small"],
                     help="heldsuarez on N > 1 GPUs: strong = the 6x30x30x8 sphere of BASELINE "
@@ -724,8 +726,128 @@ def main(argv=None):
         dist.destroy_process_group()
 
 
+def ocean_setup(cm, Nx, Nz):
+    """BASELINE configs[4]: hydrostatic Boussinesq ocean box with the split-explicit stepper
+    (test/Ocean/SplitExplicit/hydrostatic_spindown.jl:3-140, SplitExplicitSolver variant:
+    SimpleBox 1e6 x 1e6 x 400 m, 3-D HBModel + 2-D ShallowWaterModel on the one-layer extrusion
+    of the horizontal grid, periodic in x and y) at Nx x Nx x Nz elements, N = 4."""
+    O, M = cm.ocean, cm.mesh
+    Lx, Ly, H = 1e6, 1e6, 400.0
+    problem = O.SimpleBox(Lx, Ly, H, rotation=O.FIXED)
+    law3 = O.HydrostaticBoussinesqModel(problem, c_h=1.0, alpha_T=0.0, kappa_h=0.0, kappa_z=0.0,
+                                        coupled=True)
+    law2 = O.ShallowWaterModel(problem, law3.nu_h, advection=False, coupled=True, c=1.0)
+    x, y = np.linspace(0.0, Lx, Nx + 1), np.linspace(0.0, Ly, Nx + 1)
+    topl = M.StackedBrickTopology([x, y, np.linspace(-H, 0.0, Nz + 1)],
+                                  periodicity=(True, True, False),
+                                  boundary=((0, 0), (0, 0), (1, 2)))
+    grid3 = M.DiscontinuousSpectralElementGrid(topl, 4)
+    # (fields are constant along the extrusion: two nodes carry them, 50 nodes per element)
+    grid2 = O.extruded_barotropic_grid(x, y, 4, N_extrusion=1)
+    # the reference's 5 x 5 x 8 runs use dt_slow = 5400 s over dt_fast = 300 s; both scale with
+    # the horizontal element size so that the finer box stays inside the barotropic CFL limit
+    return law3, grid3, law2, grid2, 5400.0 * 5.0 / Nx, 300.0 * 5.0 / Nx
+
+
 def main_ocean(args, rank, world, local):
-    raise SystemExit("ocean-split-explicit: not built yet")
+    """``--workload ocean-split-explicit``: one "step" is one slow LSRK54 step of the 3-D model
+    (5 stages, each with its barotropic sub-steps, the two slow right-hand sides and the
+    exchanges between the models).  ``value`` counts the 3-D model's DOF updates."""
+    if world != 1:
+        raise SystemExit("ocean-split-explicit: one GPU (the partitioned split-explicit stepper is "
+                         "covered by the local-transport tests, not by this bench line)")
+    import torch
+    from cmdg_loader import cm
+    torch.cuda.set_device(local)
+    O = cm.ocean
+    Nx, Nz = args.ocean_nx, args.ocean_nz
+    t0 = time.time()
+    law3, g3, law2, g2, dt_slow, dt_fast = ocean_setup(cm, Nx, Nz)
+    log("[ocean] grids: %.1f s" % (time.time() - t0))
+    dg3 = cm.dgmodel.DGModel(law3, g3)
+    keep = O.install_hydrostatic_boussinesq_hooks(dg3)
+    dg2 = cm.dgmodel.DGModel(law2, g2,
+                             numerical_flux_first_order=cm.balancelaws.CentralNumericalFluxFirstOrder)
+    Q3, Q2 = dg3.init_ode_state(0.0), dg2.init_ode_state(0.0)
+    se = O.SplitExplicitSolver(dg3, dg2, Q3, Q2, dt_slow, dt_fast)
+    se.dostep(Q3, Q2, args.warmup)
+    dg3.synchronize(), dg2.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    se.dostep(Q3, Q2, args.steps)
+    dg3.synchronize(), dg2.synchronize()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    for d in (dg3, dg2):
+        d.profile_reset()
+        if not args.no_events:
+            d.profile_enable(True)
+    t1 = time.perf_counter()
+    se.dostep(Q3, Q2, args.steps)
+    dg3.synchronize(), dg2.synchronize()
+    torch.cuda.synchronize()
+    el_ev = time.perf_counter() - t1
+    for d in (dg3, dg2):
+        d.profile_enable(False)
+    RKC = se.RKC
+    nsub = sum(int(np.ceil(((1 - RKC[s]) if s == 4 else (RKC[s + 1] - RKC[s])) * dt_slow / dt_fast))
+               for s in range(5))
+    finite = bool(torch.isfinite(Q3[:g3.nreal]).all().item() and torch.isfinite(Q2[:g2.nreal]).all().item())
+    dofs = g3.nreal * g3.Np * law3.ns * 5 * args.steps
+    kernels = {}
+    for name, d in (("slow", dg3), ("fast", dg2)):
+        for kn in ("GRADIENTS", "TENDENCY", "FILTER", "STACK_INTEGRAL"):
+            ms, n = d.profile_get(kn)
+            if n:
+                kernels["%s_%s" % (name, kn.lower())] = {
+                    "avg_ms": ms / n, "launches_per_step": n / args.steps, "ms_per_step": ms / args.steps}
+    out = {"metric": "DG RHS DOF-updates/sec", "value": dofs / el, "unit": "DOF-updates/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "hydrostatic Boussinesq ocean box (BASELINE configs[4]), split-explicit "
+                                  "barotropic / baroclinic stepper, %dx%dx%d elements, N=4 (%d 3-D "
+                                  "elements, %d columns), dt_slow=%g s, dt_fast<=%g s (%d barotropic "
+                                  "LSRK54 steps per slow step), Coupled, fp64"
+                                  % (Nx, Nx, Nz, g3.nreal, g2.nreal, dt_slow, dt_fast, nsub),
+                      "elements": int(g3.nreal), "nodes_per_element": int(g3.Np), "states": law3.ns,
+                      "parallelism": "1 rank"},
+           "node_updates_per_s": dofs / el / law3.ns, "state_finite": finite, "kernels_ms": kernels}
+    if "slow_tendency" in kernels:
+        info = kernel_info(dg3, law3, g3, (0, 0))
+        avg_ms = kernels["slow_tendency"]["avg_ms"]
+        needed = needed_bytes_per_node(info, "TENDENCY") - 8 * 1.5 * law3.ns
+        # (the slow model's update! is a launch of its own: the pass writes dQ, and reads it in the
+        # increment = true call of the stage, not in the increment = false one)
+        nodes = g3.nreal * g3.Np
+        achieved = needed * nodes / (avg_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_tendency (3-D HBModel)", "achieved": achieved,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": None, "algorithmic_bytes_per_launch": needed * nodes,
+                           "algorithmic_bytes_per_node": needed, "avg_launch_ms": avg_ms,
+                           "timing": "HIP events on the launch stream, second pass of the same %d "
+                                     "steps (%.3f ms/step with events)" % (args.steps, 1e3 * el_ev / args.steps)}
+    if not args.no_cpu:
+        from oracle import oracle as OR
+        OR.build()
+        F = cm.mesh.filters
+        o3 = OR.OracleDGModel(law3, g3)
+        OR.hydrostatic_boussinesq_hooks(o3, F.CutoffFilter(g3, 3), F.ExponentialFilter(g3, 1, 8))
+        o2 = OR.OracleDGModel(law2, g2, nf_first=1)
+        q3 = law3.init_state_prognostic(g3, o3.state_auxiliary, 0.0)
+        q2 = law2.init_state_prognostic(g2, o2.state_auxiliary, 0.0)
+        so = OR.SplitExplicitOracle(o3, o2, q3, q2, dt_slow, dt_fast)
+        t0 = time.perf_counter()
+        so.dostep(q3, q2, 0.0)
+        c = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": g3.nreal * g3.Np * law3.ns * 5 / c, "unit": "DOF-updates/s",
+                               "cores": OR.get_max_threads(), "kind": "port",
+                               "sample": "1 slow step of the same workload in %.1f s, OpenMP over elements" % c}
+    print(json.dumps(out), flush=True)
+    del keep
+    dg3.close(), dg2.close()
+    if not finite:
+        raise SystemExit("bench.py: the state is not finite after the timed steps")
 
 
 if __name__ == "__main__":

@@ -196,10 +196,16 @@ int EngineBase::init(const cmdg_desc *d)
     HIPCHK(hipGetDevice(&dev));
     HIPCHK(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
     {
-        // the halo stream carries the latency chain of a partitioned run (exchange -> exterior
-        // launch -> exchange ...): its small kernels go ahead of the interior launches' blocks
+        // CMDG_HALO_PRIORITY=1: the halo stream (the latency chain of a partitioned run: exchange ->
+        // exterior launch -> exchange ...) as a high-priority stream, so that its small kernels go
+        // ahead of the interior launches' blocks.  Off by default: it gains nothing measurable at
+        // 5 400 elements per rank (profiles/r03_halo_exposure_*), and with the slow and the fast
+        // model of the split-explicit ocean both on priority streams the two-rank local-transport
+        // test fails reproducibly (passes with either one alone, with three ranks, and with
+        // AMD_SERIALIZE_KERNEL=3): an ordering the events express is not kept -- unexplained.
         int lo = 0, hi = 0;
-        if (communicate() && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
+        const char *pv = getenv("CMDG_HALO_PRIORITY");
+        if (communicate() && pv && *pv == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
             HIPCHK(hipStreamCreateWithPriority(&s_comm, hipStreamNonBlocking, hi));
         else
             HIPCHK(hipStreamCreateWithFlags(&s_comm, hipStreamNonBlocking));
@@ -282,6 +288,9 @@ int EngineBase::init(const cmdg_desc *d)
     HIPCHK(hipMalloc(&d_partial, sizeof(double) * 1024));
     if (communicate())
         if (int r = init_halo_tables()) return r;
+    // debugging overrides of the two exchange options (cmdg_set_option still has the last word)
+    if (const char *v = getenv("CMDG_REFERENCE_HALO")) reference_halo = *v && *v != '0';
+    if (const char *v = getenv("CMDG_HALO_PIPELINE")) no_pipeline = *v == '0';
     return init_derived();
 }
 

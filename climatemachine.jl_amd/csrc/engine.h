@@ -384,9 +384,19 @@ struct EngineT : EngineBase {
         args.h = halo_dev(exterior, c.lsrk ? slot[SLOT_Q].sendbuf : nullptr, nullptr);
         const bool recv = args.h.ghostslot != nullptr && exterior;  // (interior elements have no ghost neighbour)
         if (!recv) args.h.ghostslot = nullptr;
+        // large elements: volume half, then interface half + update (TendencyShape::SPLIT)
 #define CMDG_TEND(L, G)                                                                             \
     do {                                                                                            \
-        if (recv)                                                                                   \
+        if constexpr (SH::SPLIT) {                                                                  \
+            hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, false, G, false, TEND_VOLUME>), grid,      \
+                               dim3(SH::NTV), 0, st, args);                                         \
+            if (recv)                                                                               \
+                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, L, G, true, TEND_FACES>), grid, block, \
+                                   0, st, args);                                                    \
+            else                                                                                    \
+                hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, L, G, false, TEND_FACES>), grid,       \
+                                   block, 0, st, args);                                             \
+        } else if (recv)                                                                            \
             hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, L, G, true>), grid, block, 0, st, args);   \
         else                                                                                        \
             hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, L, G, false>), grid, block, 0, st, args);  \

@@ -37,6 +37,18 @@
 #ifndef CMDG_LAP_MINW
 #define CMDG_LAP_MINW 1
 #endif
+// tendency pass of large elements (N >= 5) in two launches, volume then interface + update
+// (see TendencyShape::SPLIT; off: measured slower than two elements per work-group), and the
+// register budgets asked for the two halves (waves per SIMD)
+#ifndef CMDG_TEND_SPLIT_LARGE
+#define CMDG_TEND_SPLIT_LARGE 0
+#endif
+#ifndef CMDG_TENDV_MINW
+#define CMDG_TENDV_MINW 4
+#endif
+#ifndef CMDG_TENDF_MINW
+#define CMDG_TENDF_MINW 4
+#endif
 
 namespace cmdg {
 
@@ -335,12 +347,26 @@ struct grad_min_waves<P, std::void_t<decltype(P::GRAD_MIN_WAVES)>> : std::integr
 // VGPRs (profiles/r02_lds_occupancy.jsonl).  Two elements per work-group (686 threads, eleven
 // waves, 3-3-3-2) even that out; the minus side of the faces is then read from memory instead
 // of being staged, so that both elements' flux buffers fit the LDS of a CU.
+//
+// SPLIT (large elements): the pass in two launches with separate register budgets, as the
+// reference has them (volume_tendency! / dgsem_interface_tendency!, DGModel_kernels.jl:64-548 /
+// :588-901) -- k_tendency<..., TEND_VOLUME> forms the volume part and stores it, k_tendency<...,
+// TEND_FACES> reads it back, adds the lifted face fluxes in the same order and applies the fused
+// update.  Measured on BOMEX (N = 6, 8 192 elements, profiles/r03_ab_bomex_split.txt): the two
+// launches take 727 us against 603 us for the fused two-element work-group -- the interface half
+// still needs 167-181 VGPRs and 73 KB of LDS (two six-wave work-groups per CU at best, no more
+// waves than the fused kernel's eleven), and the round trip of the tendency comes on top.  Kept
+// behind CMDG_TEND_SPLIT_LARGE as the recorded loser.
+enum { TEND_FUSED = 0, TEND_VOLUME = 1, TEND_FACES = 2 };
 template <class P, int NQ, int NQV>
 struct TendencyShape {
     using KD = KDims<NQ, NQV>;
-    static constexpr int EPB = (KD::Np > 125 && node_cache_size<P>::value == 0) ? CMDG_TEND_EPB_LARGE : 1;
+    static constexpr bool SPLIT = KD::Np > 125 && node_cache_size<P>::value == 0 && CMDG_TEND_SPLIT_LARGE != 0;
+    static constexpr int EPB =
+        (!SPLIT && KD::Np > 125 && node_cache_size<P>::value == 0) ? CMDG_TEND_EPB_LARGE : 1;
     static constexpr int NTE = EPB == 1 ? KD::NT : (KD::Np > KD::NFT ? KD::Np : KD::NFT);
     static constexpr int NT = EPB == 1 ? KD::NT : ((EPB * NTE + 63) / 64) * 64;
+    static constexpr int NTV = ((KD::Np + 63) / 64) * 64;  // threads of the volume half
     static int64_t blocks(int64_t nelems) { return (nelems + EPB - 1) / EPB; }
 };
 
@@ -351,27 +377,38 @@ struct TendencyShape {
 // handle whose exchanges are not unpacked).  A variant of its own: the second addressing mode
 // costs the Held-Suarez instantiation 24 VGPRs (128 -> 150, one wave per SIMD less), which the
 // interior launches and single-rank handles do not pay.
-template <class P, int NQ, int NQV, bool LSRK, bool USE_GF, bool RECV = false>
-__global__ void __launch_bounds__((TendencyShape<P, NQ, NQV>::NT), CMDG_TEND_MINW) k_tendency(const PassArgs<P> a)
+template <class P, int NQ, int NQV, int MODE>
+constexpr int tendency_threads()
+{
+    return MODE == TEND_VOLUME ? TendencyShape<P, NQ, NQV>::NTV : TendencyShape<P, NQ, NQV>::NT;
+}
+template <class P, int NQ, int NQV, bool LSRK, bool USE_GF, bool RECV = false, int MODE = TEND_FUSED>
+__global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, MODE>()),
+                                   (MODE == TEND_FUSED ? CMDG_TEND_MINW
+                                                       : (MODE == TEND_VOLUME ? CMDG_TENDV_MINW : CMDG_TENDF_MINW)))
+    k_tendency(const PassArgs<P> a)
 {
     using KD = KDims<NQ, NQV>;
     using SH = TendencyShape<P, NQ, NQV>;
     constexpr int EPB = SH::EPB;
+    constexpr bool VOL = MODE != TEND_FACES, FACES = MODE != TEND_VOLUME;
+    static_assert(MODE == TEND_FUSED || (EPB == 1 && node_cache_size<P>::value == 0),
+                  "the two-launch form takes one element per work-group and no node cache");
     constexpr bool STAGE_M = EPB == 1;
     constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGF = P::NGF,
                   NHYP = P::NHYP, NHG = 3 * P::NGL, NFA = P::NFAUX,
                   NSURF = SurfDims<NQ, NQV>::NSURF, NGFS = USE_GF ? NGF : 0,
                   NCA = node_cache_size<P>::value,
-                  NMF = (STAGE_M ? NFA + NGFS + NHYP : 0) + NCA, OCA = NMF - NCA;
-    __shared__ double sD[NQ * NQ + (NQV == NQ ? 0 : NQV * NQV)];
+                  NMF = (STAGE_M && FACES ? NFA + NGFS + NHYP : 0) + NCA, OCA = NMF - NCA;
+    __shared__ double sD[VOL ? NQ * NQ + (NQV == NQ ? 0 : NQV * NQV) : 1];
     const double *const sDv = sD + (NQV == NQ ? 0 : NQ * NQ);  // vertical derivative matrix
-    // contravariant flux [d][s][ijk]; later the accumulator
-    __shared__ double sF_[EPB * 3 * NS * Np];
+    // contravariant flux [d][s][ijk]; later the accumulator (interface half alone: the accumulator)
+    __shared__ double sF_[EPB * (VOL ? 3 : 1) * NS * Np];
     // minus side, surface nodes [field][sidx]
     __shared__ double sM_[EPB * (NMF > 0 ? NMF : 1) * (NMF > 0 ? NSURF : 1)];
     // the prognostic state of every node: minus side of the faces, and the "Q" of the fused
     // update at the end (re-reading it from memory 20 us after the first read misses L2)
-    __shared__ double sQ_[EPB * NS * Np];
+    __shared__ double sQ_[FACES ? EPB * NS * Np : 1];
     // this thread's element of the work-group and its index there
     const int sub = EPB == 1 ? 0 : (int)threadIdx.x / SH::NTE;
     const int tid = EPB == 1 ? (int)threadIdx.x : (int)threadIdx.x - sub * SH::NTE;
@@ -379,13 +416,15 @@ __global__ void __launch_bounds__((TendencyShape<P, NQ, NQV>::NT), CMDG_TEND_MIN
     const bool live = EPB == 1 || (sub < EPB && li < a.nelems);
     const int64_t e = live ? a.elems[li] - 1 : 0;
     const int lsub = live ? sub : 0;
-    double *const sF = sF_ + lsub * (3 * NS * Np);
+    double *const sF = sF_ + lsub * ((VOL ? 3 : 1) * NS * Np);
     double *const sM = sM_ + lsub * ((NMF > 0 ? NMF : 1) * (NMF > 0 ? NSURF : 1));
-    double *const sQ = sQ_ + lsub * (NS * Np);
+    double *const sQ = sQ_ + (FACES ? lsub * (NS * Np) : 0);
     double *const sT = sF;              // tendency accumulator [s][ijk] (aliases sF after phase 2)
-    if (threadIdx.x < NQ * NQ) sD[threadIdx.x] = a.g.D[threadIdx.x];
-    if constexpr (NQV != NQ) {
-        if (threadIdx.x < NQV * NQV) sD[NQ * NQ + threadIdx.x] = a.g.Dv[threadIdx.x];
+    if constexpr (VOL) {
+        if (threadIdx.x < NQ * NQ) sD[threadIdx.x] = a.g.D[threadIdx.x];
+        if constexpr (NQV != NQ) {
+            if (threadIdx.x < NQV * NQV) sD[NQ * NQ + threadIdx.x] = a.g.Dv[threadIdx.x];
+        }
     }
     const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
     // USE_GF: does flux_second_order depend on the gradient-flux state at all?  With zero
@@ -394,8 +433,8 @@ __global__ void __launch_bounds__((TendencyShape<P, NQ, NQV>::NT), CMDG_TEND_MIN
     constexpr bool use_gf = NGF > 0 && USE_GF;
     int32_t f_idP = 0;
     int f_bctag = 0;
-    bool face_on;
-    {
+    bool face_on = false;
+    if constexpr (FACES) {
         int f_f = 0, f_n = 0;
         KD::face_task(tid, f_f, f_n);
         face_on = live && tid < KD::NFT && (f_f < 4 ? hz : vt);
@@ -403,7 +442,33 @@ __global__ void __launch_bounds__((TendencyShape<P, NQ, NQV>::NT), CMDG_TEND_MIN
     }
     Vec<NS> S;
     double MI = 0;
-    if (live && tid < Np) {
+    if constexpr (MODE == TEND_FACES) {
+        // interface half: the volume part of the tendency (the other launch stored it), the
+        // state, and the minus side of the surface nodes
+        if (live && tid < Np) {
+            const int sidx = surf_index<NQ, NQV>(tid);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int64_t o = tid + (int64_t)Np * (s + (int64_t)NS * e);
+                sT[s * Np + tid] = a.tendency[o];
+                sQ[s * Np + tid] = a.Q[o];
+            }
+            if (sidx >= 0) {
+#pragma unroll
+                for (int s = 0; s < NFA; ++s)
+                    sM[s * NSURF + sidx] = a.aux[tid + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * e)];
+                if (use_gf) {
+#pragma unroll
+                    for (int s = 0; s < NGF; ++s)
+                        sM[(NFA + s) * NSURF + sidx] = a.gf[tid + (int64_t)Np * (s + (int64_t)NGF * e)];
+                }
+#pragma unroll
+                for (int s = 0; s < NHYP; ++s)
+                    sM[(NFA + NGFS + s) * NSURF + sidx] = a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)];
+            }
+        }
+    }
+    if (VOL && live && tid < Np) {
         const double *vg = a.g.vgeo + (int64_t)Np * a.g.nvgeo * e + tid;
         const double M = vg[VM * Np];
         MI = vg[VMI * Np];
@@ -420,9 +485,11 @@ __global__ void __launch_bounds__((TendencyShape<P, NQ, NQV>::NT), CMDG_TEND_MIN
         for (int s = 0; s < NHYP; ++s)
             lhyp[s] = a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)];
         const int sidx = surf_index<NQ, NQV>(tid);
+        if constexpr (FACES) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) sQ[s * Np + tid] = lQ[s];
-        if (STAGE_M && sidx >= 0) {  // stage the minus side of the interface phase
+            for (int s = 0; s < NS; ++s) sQ[s * Np + tid] = lQ[s];
+        }
+        if (FACES && STAGE_M && sidx >= 0) {  // stage the minus side of the interface phase
 #pragma unroll
             for (int s = 0; s < NFA; ++s) sM[s * NSURF + sidx] = laux[P::face_aux(s)];
             if (use_gf) {
@@ -479,7 +546,7 @@ __global__ void __launch_bounds__((TendencyShape<P, NQ, NQV>::NT), CMDG_TEND_MIN
     }
     __syncthreads();
     Vec<NS> Tv;
-    if (live && tid < Np) {
+    if (VOL && live && tid < Np) {
         const int i = tid % NQ, j = (tid / NQ) % NQ, k = tid / (NQ * NQ);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -520,10 +587,19 @@ __global__ void __launch_bounds__((TendencyShape<P, NQ, NQV>::NT), CMDG_TEND_MIN
             Tv[s] = T;
         }
     }
-    __syncthreads();  // every read of sF is done: it becomes the accumulator sT
-    if (live && tid < Np) {
+    if constexpr (MODE == TEND_VOLUME) {  // volume half: store, the interface launch goes on from here
+        if (live && tid < Np) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) sT[s * Np + tid] = Tv[s];
+            for (int s = 0; s < NS; ++s) a.tendency[tid + (int64_t)Np * (s + (int64_t)NS * e)] = Tv[s];
+        }
+        return;
+    }
+    if constexpr (MODE == TEND_FUSED) {
+        __syncthreads();  // every read of sF is done: it becomes the accumulator sT
+        if (live && tid < Np) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sT[s * Np + tid] = Tv[s];
+        }
     }
     // ---- faces: dgsem_interface_tendency! ------------------------------------------
     Vec<NS> lift;

@@ -292,3 +292,31 @@ def test_rotating_split_explicit_steps_match_oracle(cm, oracle, torch):
     for s in (0, 1, 2):
         assert _scaled(Qn2[:, s], Q2[:, s]) < TOL, s
     _close(dg3, dg2, keep)
+
+
+def test_full_size_ocean_box_properties(cm, torch):
+    """BASELINE configs[4] at the size ``bench.py --workload ocean-split-explicit`` runs
+    (48 x 48 x 16 elements, 36 864 three-dimensional elements, 2 304 columns), where the oracle is
+    too slow: (1) determinism -- two runs of two slow steps from the same state are bit identical
+    (every accumulation has a fixed order, the two streams are ordered by events); (2) the
+    barotropic continuity equation conserves the volume: the integral of eta over the periodic
+    box stays at its initial value to rounding; (3) everything stays finite."""
+    import bench
+    law3, g3, law2, g2, dt_slow, dt_fast = bench.ocean_setup(cm, 48, 16)
+    assert g3.nreal == 36864 and g2.nreal == 2304
+    runs = []
+    for _ in range(2):
+        dg3, dg2, keep = _device_pair(cm, torch, law3, g3, law2, g2)
+        Q3, Q2 = dg3.init_ode_state(0.0), dg2.init_ode_state(0.0)
+        M2 = dg2._vgeo[:g2.nreal, 9, :]
+        eta0 = (M2 * Q2[:g2.nreal, 0, :]).sum().item()
+        scale = (M2 * Q2[:g2.nreal, 0, :].abs()).sum().item()
+        se = cm.ocean.SplitExplicitSolver(dg3, dg2, Q3, Q2, dt_slow, dt_fast)
+        se.dostep(Q3, Q2, 2)
+        eta1 = (M2 * Q2[:g2.nreal, 0, :]).sum().item()
+        assert abs(eta1 - eta0) < 1e-11 * scale, (eta0, eta1, scale)
+        assert torch.isfinite(Q3[:g3.nreal]).all() and torch.isfinite(Q2[:g2.nreal]).all()
+        assert (Q2[:g2.nreal, 0, :] != dg2.init_ode_state(0.0)[:g2.nreal, 0, :]).any()
+        runs.append((Q3[:g3.nreal].clone(), Q2[:g2.nreal].clone()))
+        _close(dg3, dg2, keep)
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
