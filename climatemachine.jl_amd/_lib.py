@@ -79,7 +79,8 @@ class CmdgRhsHooks(C.Structure):
 class CmdgOcean01Desc(C.Structure):
     """``cmdg_ocean01_desc`` of include/cmdg.h."""
     _fields_ = [("nvertelem", C.c_int32), ("H", C.c_double), ("Imat", C.c_void_p),
-                ("add_fast_substeps", C.c_int32)]
+                ("add_fast_substeps", C.c_int32), ("nstages_fast", C.c_int32),
+                ("rka_fast", C.c_void_p), ("rkb_fast", C.c_void_p), ("rkc_fast", C.c_void_p)]
 
 
 class CmdgOceanCouplingDesc(C.Structure):

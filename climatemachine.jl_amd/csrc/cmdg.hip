@@ -957,8 +957,16 @@ int EngineBase::stack_integral(bool reverse, const double *Q, int nstate, double
 // ---- law-specific update_auxiliary_state! / update_auxiliary_state_gradient! as hooks ----
 int EngineBase::set_hooks(const cmdg_rhs_hooks *hk)
 {
+    auto forget_child = [&]() {  // this handle no longer evaluates its former nested operator
+        if (has_hooks && hooks.pre_rhs_handle && hooks.pre_rhs_handle->eng) {
+            auto &v = hooks.pre_rhs_handle->eng->nested_in;
+            v.erase(std::remove(v.begin(), v.end(), this), v.end());
+        }
+    };
     if (!hk) {
+        forget_child();
         has_hooks = false;
+        hooks.pre_rhs_handle = nullptr;
         return CMDG_OK;
     }
     if (hk->npre < 0 || hk->npre > CMDG_MAX_HOOK_OPS || hk->ncopy < 0 || hk->ncopy > CMDG_MAX_HOOK_OPS ||
@@ -1000,9 +1008,11 @@ int EngineBase::set_hooks(const cmdg_rhs_hooks *hk)
         if (!d_Imat) HIPCHK(hipMalloc(&d_Imat, sizeof(double) * NQ * NQ));
         HIPCHK(hipMemcpy(d_Imat, hk->Imat, sizeof(double) * NQ * NQ, hipMemcpyHostToDevice));
     }
+    forget_child();
     hooks = *hk;
     hooks.Imat = nullptr;
     has_hooks = true;
+    if (hooks.pre_rhs_handle) hooks.pre_rhs_handle->eng->nested_in.push_back(this);
     return CMDG_OK;
 }
 
@@ -1369,6 +1379,16 @@ int cmdg_destroy(cmdg_handle h)
     if (!h) return CMDG_ERR_INVALID;
     {
         DevGuard guard_(h->eng);
+        // handles whose hooks evaluate this one as their nested operator go on without it, and
+        // the nested operator of this handle forgets its parent
+        for (EngineBase *parent : h->eng->nested_in) {
+            parent->synchronize();
+            parent->hooks.pre_rhs_handle = nullptr;
+        }
+        if (h->eng->has_hooks && h->eng->hooks.pre_rhs_handle && h->eng->hooks.pre_rhs_handle->eng) {
+            auto &v = h->eng->hooks.pre_rhs_handle->eng->nested_in;
+            v.erase(std::remove(v.begin(), v.end(), h->eng), v.end());
+        }
         // members of a local group keep pointers to each other: detach the survivors
         for (EngineBase *peer : h->eng->group)
             if (peer && peer != h->eng) {
@@ -1421,8 +1441,9 @@ int cmdg_lsrk_run(cmdg_handle h, double *Q, double *dQ, double t, double dt, int
 {
     if (!h || !Q || !dQ || !rka || !rkb || !rkc) return CMDG_ERR_INVALID;
     DevGuard guard_(h->eng);
-    for (int64_t i = 0; i < nsteps; ++i) {
-        int r = h->eng->lsrk_step(Q, dQ, t + i * dt, dt, nstages, rka, rkb, rkc, i > 0);
+    // (the step times accumulate as the reference's updatetime! does: t += dt, ODESolvers.jl:96-98)
+    for (int64_t i = 0; i < nsteps; ++i, t += dt) {
+        int r = h->eng->lsrk_step(Q, dQ, t, dt, nstages, rka, rkb, rkc, i > 0);
         if (r) return set_err(h, r);
     }
     return CMDG_OK;
@@ -1653,8 +1674,8 @@ int cmdg_group_lsrk_run(cmdg_handle *handles, int32_t n, double **Q, double **dQ
     DevGuard guard_(handles[0]->eng);
     std::vector<EngineBase *> g;
     for (int i = 0; i < n; ++i) g.push_back(handles[i]->eng);
-    for (int64_t s = 0; s < nsteps; ++s) {
-        int r = group_lsrk_step(g, Q, dQ, t + s * dt, dt, nstages, rka, rkb, rkc, s > 0);
+    for (int64_t s = 0; s < nsteps; ++s, t += dt) {
+        int r = group_lsrk_step(g, Q, dQ, t, dt, nstages, rka, rkb, rkc, s > 0);
         if (r) {
             for (int i = 0; i < n; ++i) set_err(handles[i], r);
             return r;

@@ -80,10 +80,12 @@ __global__ __launch_bounds__(256) void k_stack_integral(StackArgs a)
                 lint[s][k] = lint[s][NQ - 1];
             }
         }
+        if (ev + 1 < a.nvert) {  // (nothing was prefetched behind the last element)
 #pragma unroll
-        for (int s = 0; s < NOUT; ++s)
+            for (int s = 0; s < NOUT; ++s)
 #pragma unroll
-            for (int k = 0; k < NQ; ++k) lker[s][k] = lnext[s][k];
+                for (int k = 0; k < NQ; ++k) lker[s][k] = lnext[s][k];
+        }
     }
 }
 
@@ -127,10 +129,12 @@ __global__ __launch_bounds__(256) void k_reverse_stack_integral(StackArgs a)
             for (int s = 0; s < NOUT; ++s)
                 a.aux[ijk + (int64_t)Np * (a.dst[s] + (int64_t)a.naux * e)] = lT[s] - v[s][k];
         }
+        if (ev + 1 < a.nvert) {
 #pragma unroll
-        for (int s = 0; s < NOUT; ++s)
+            for (int s = 0; s < NOUT; ++s)
 #pragma unroll
-            for (int k = 0; k < NQ; ++k) v[s][k] = vnext[s][k];
+                for (int k = 0; k < NQ; ++k) v[s][k] = vnext[s][k];
+        }
     }
 }
 

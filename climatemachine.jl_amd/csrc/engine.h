@@ -243,6 +243,9 @@ struct EngineBase {
                        int64_t h0 = 0, int64_t nh = -1);
     bool has_hooks = false;
     cmdg_rhs_hooks hooks{};
+    // handles whose hooks evaluate this one as their nested operator (hooks.pre_rhs_handle):
+    // cmdg_destroy of this handle detaches it from them
+    std::vector<EngineBase *> nested_in;
     int set_hooks(const cmdg_rhs_hooks *hk);
     int run_pre_hooks(const RhsCtx &c);
     int integrate_velocity(const double *X, int nstate, int col, int nvert, int64_t h0 = 0,

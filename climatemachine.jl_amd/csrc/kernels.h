@@ -26,6 +26,11 @@
 #ifndef CMDG_TEND_EPB_LARGE
 #define CMDG_TEND_EPB_LARGE 2
 #endif
+// ... and for N <= 4 (one: 192 threads, minus side of the faces staged in LDS; two measured
+// slower on Held-Suarez and on the rising bubble, profiles/r03_ab_two_elements_n4.txt)
+#ifndef CMDG_TEND_EPB_SMALL
+#define CMDG_TEND_EPB_SMALL 1
+#endif
 // k_gradients: the Held-Suarez instantiation needs 130 VGPRs unconstrained (3 waves/SIMD);
 // asking for 4 gives 128 without scratch and 9 % less time per launch (profiles/r01_ab_*.txt)
 #ifndef CMDG_GRAD_MINW
@@ -362,8 +367,9 @@ template <class P, int NQ, int NQV>
 struct TendencyShape {
     using KD = KDims<NQ, NQV>;
     static constexpr bool SPLIT = KD::Np > 125 && node_cache_size<P>::value == 0 && CMDG_TEND_SPLIT_LARGE != 0;
-    static constexpr int EPB =
-        (!SPLIT && KD::Np > 125 && node_cache_size<P>::value == 0) ? CMDG_TEND_EPB_LARGE : 1;
+    static constexpr int EPB = node_cache_size<P>::value != 0 || SPLIT
+                                   ? 1
+                                   : (KD::Np > 125 ? CMDG_TEND_EPB_LARGE : CMDG_TEND_EPB_SMALL);
     static constexpr int NTE = EPB == 1 ? KD::NT : (KD::Np > KD::NFT ? KD::Np : KD::NFT);
     static constexpr int NT = EPB == 1 ? KD::NT : ((EPB * NTE + 63) / 64) * 64;
     static constexpr int NTV = ((KD::Np + 63) / 64) * 64;  // threads of the volume half

@@ -63,6 +63,12 @@ struct MoistAtmos {
                                          : (i == 6 ? OTURB : (i == 7 ? OMOIST : OMOIST + i - 6))));
     }
     __host__ __device__ static constexpr int hv_indexmap(int) { return 0; }
+    // Byte accounting (cmdg_query, bench.py): columns the volume code of a pass reads.  Gradients
+    // (pass 0): the refreshed equilibrium state (temperature, theta_v, q_liq, q_ice) and grad Phi
+    // (N^2); tendency (pass 3): the ten columns of face_aux (Phi, grad Phi, ref rho, ref p, Delta,
+    // temperature, q_liq, q_ice) -- coord, the rest of ref_state and theta_v are never loaded.
+    __host__ __device__ static constexpr int state_read(int) { return NS; }
+    __host__ __device__ static constexpr int aux_read(int pass) { return pass == 0 ? 7 : (pass == 3 ? 10 : 0); }
     __host__ __device__ static bool needs_gradflux(const Params &) { return true; }
     __host__ __device__ static bool update_aux_active(const Params &) { return true; }
 

@@ -141,6 +141,16 @@ extern "C" int cmdg_split_explicit01_step(cmdg_handle slow, cmdg_handle fast, co
         return bad("split explicit 01: grids / parameters");
     if (S->communicate() || F->communicate())
         return bad("split explicit 01: single rank only");
+    if (F->dev != S->dev)  // the fast launches and the events between the two engines assume one device
+        return bad("split explicit 01: the slow and the fast handle live on one device");
+    // dostep!(Qfast, fast, ...) runs the FAST solver's scheme (SplitExplicitLSRK2nMethod.jl:150-165):
+    // its own tableau when the caller gives one, the slow solver's otherwise
+    const int nst_f = d->nstages_fast > 0 ? d->nstages_fast : nstages;
+    const double *rka_f = d->nstages_fast > 0 ? d->rka_fast : rka;
+    const double *rkb_f = d->nstages_fast > 0 ? d->rkb_fast : rkb;
+    const double *rkc_f = d->nstages_fast > 0 ? d->rkc_fast : rkc;
+    if (d->nstages_fast < 0 || (d->nstages_fast > 0 && (!rka_f || !rkb_f || !rkc_f)))
+        return bad("split explicit 01: the fast solver's tableau");
     if (!S->d_Imat) {
         if (!d->Imat) return bad("split explicit 01: Imat is NULL");
         if (hipMalloc(&S->d_Imat, sizeof(double) * S->NQ * S->NQ) != hipSuccess ||
@@ -216,7 +226,7 @@ extern "C" int cmdg_split_explicit01_step(cmdg_handle slow, cmdg_handle fast, co
         // ---- barotropic sub-steps with cummulate_fast_solution! (Communication.jl:226-252)
         for (int sub = 1; sub <= fs3; ++sub) {
             const double fast_time = stage_time + (sub - 1) * fdt;
-            if (int r = group_lsrk_step(Fv, Q2v, dQ2v, fast_time, fdt, nstages, rka, rkb, rkc))
+            if (int r = group_lsrk_step(Fv, Q2v, dQ2v, fast_time, fdt, nst_f, rka_f, rkb_f, rkc_f))
                 return fail_from(F, r);
             if (sub >= fs1) {
                 fcols(F->aux, B::NAUX, B::AUC, Q2, B::NS, B::U1, 2, 1, F->s_comp);

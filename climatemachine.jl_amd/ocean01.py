@@ -190,7 +190,10 @@ class SplitExplicitLSRK2nSolver01:
     """``SplitExplicitLSRK2nSolver(slow_solver, fast_solver)`` (SplitExplicitLSRK2nMethod.jl:40-78)
     over the device operators: ``dostep`` = ``cmdg_split_explicit01_step``."""
 
-    def __init__(self, ocean_dg, dg_fast, Q_slow, Q_fast, dt_slow, dt_fast, t0=0.0):
+    def __init__(self, ocean_dg, dg_fast, Q_slow, Q_fast, dt_slow, dt_fast, t0=0.0,
+                 fast_coefficients=None):
+        """``fast_coefficients``: ``(RKA, RKB, RKC)`` of the fast solver when it is not the slow
+        solver's scheme (the reference builds both from LSRK54CarpenterKennedy)."""
         from . import _lib
         from .odesolvers import LSRK54CarpenterKennedy
         self._lib = _lib
@@ -207,6 +210,10 @@ class SplitExplicitLSRK2nSolver01:
         self._Imat = np.ascontiguousarray(np.asarray(g.Imat[-1], dtype=np.float64).T)
         d.Imat = self._Imat.ctypes.data
         d.add_fast_substeps = int(model.add_fast_substeps)
+        if fast_coefficients is not None:
+            self._fast = tuple(np.ascontiguousarray(c, dtype=np.float64) for c in fast_coefficients)
+            d.nstages_fast = len(self._fast[0])
+            d.rka_fast, d.rkb_fast, d.rkc_fast = (c.ctypes.data for c in self._fast)
         self.desc = d
 
     def dostep(self, Q_slow, Q_fast, nsteps=1):

@@ -112,12 +112,12 @@ class StrongStabilityPreservingRungeKutta:
         dt = self.dt if dt is None else dt
         p = lambda a: C.c_void_p(a.ctypes.data)
         self.dg._torch_ready()
-        for i in range(int(nsteps)):
+        for i in range(int(nsteps)):     # each step starts at the running sum, as cmdg_lsrk_run's do
             _lib.check(self.dg.L.cmdg_ssprk_step(
                 self.dg.handle, Q.data_ptr(), self.Rstage.data_ptr(), self.Qstage.data_ptr(),
-                float(self.t + i * dt), float(dt), len(self.RKB), p(self.RKA), p(self.RKB),
+                float(self.t), float(dt), len(self.RKB), p(self.RKA), p(self.RKB),
                 p(self.RKC)), self.dg.handle)
-        _advance(self, nsteps, dt)
+            _advance(self, 1, dt)
 
 
 def _ssp(name):
@@ -165,9 +165,9 @@ class LowStorageRungeKutta3N:
         for i in range(int(nsteps)):
             _lib.check(self.dg.L.cmdg_ls3n_step(
                 self.dg.handle, Q.data_ptr(), self.dQ.data_ptr(), self.dR.data_ptr(),
-                float(self.t + i * dt), float(dt), len(self.RKC), p(self.RKA), p(self.RKB),
+                float(self.t), float(dt), len(self.RKC), p(self.RKA), p(self.RKB),
                 p(self.RKC)), self.dg.handle)
-        _advance(self, nsteps, dt)
+            _advance(self, 1, dt)
 
 
 def _ls3n(name):

@@ -119,7 +119,17 @@ const char *cmdg_status_string(int status);
 int cmdg_physics_counts(int32_t physics_id, const int32_t *iparam, int32_t out[6]);
 
 /* ---- lifetime ----------------------------------------------------------------- */
-/* replaces DGModel(...) construction, DGModel.jl:22-65 */
+/* replaces DGModel(...) construction, DGModel.jl:22-65.
+ * Preconditions on the grid tables, checked on the device at create (CMDG_ERR_INVALID with the
+ * message in cmdg_last_error(NULL) otherwise) -- every grid DiscontinuousSpectralElementGrid
+ * builds satisfies them:
+ *   - vmapM is the canonical face numbering of Grids.jl:586-594 (vmapM[n, f, e] = the volume node
+ *     of face node n of face f of element e): the kernels compute it instead of loading it;
+ *   - sgeo's vMI equals vgeo's MI at the face node, bit for bit (Grids.jl:1097-1101);
+ *   - plus-side node ids fit 32 bits (nelem * Np < 2^31).
+ * The handle keeps a digest of the face tables of its own next to the caller's arrays: 36 B per
+ * face node of the real elements (int32 plus-side node + normal + sM); handles with neighbours
+ * add 8 B per node of vmapsend and 4 B per ghost node. */
 int cmdg_create(const cmdg_desc *desc, cmdg_handle *out);
 int cmdg_destroy(cmdg_handle h);
 /* message of the last failure on this handle (never NULL) */
@@ -142,7 +152,8 @@ int cmdg_rhs_async(cmdg_handle h, double *tendency, double *Q, double t, double 
 int cmdg_lsrk_step(cmdg_handle h, double *Q, double *dQ, double t, double dt, int32_t nstages,
                    const double *rka, const double *rkb, const double *rkc);
 /* nsteps back-to-back steps of size dt starting at t (solve! loop body,
- * ODESolvers.jl:110-158 without callbacks) */
+ * ODESolvers.jl:110-158 without callbacks); step i starts at the running sum t + dt + ... + dt,
+ * as updatetime! accumulates it (ODESolvers.jl:96-98) */
 int cmdg_lsrk_run(cmdg_handle h, double *Q, double *dQ, double t, double dt, int64_t nsteps,
                   int32_t nstages, const double *rka, const double *rkb, const double *rkc);
 int cmdg_synchronize(cmdg_handle h);
@@ -372,7 +383,9 @@ typedef struct cmdg_rhs_hooks {
      *   column pre_rhs_src_col of its tendency goes to auxiliary column pre_rhs_dst_aux_col;
      *   then, with ops_before_gradients != 0, the integral / reverse integral / surface
      *   operations above run here instead of after the gradient pass; then the flow deviation.
-     * Single rank only (the nested operator would need its own ghost exchange). */
+     * Single rank only (the nested operator would need its own ghost exchange).
+     * Lifetime: the nested handle may be destroyed first -- cmdg_destroy detaches it from every
+     * handle whose hooks name it (their hooks then run without the nested operator). */
     int32_t ops_before_gradients;
     cmdg_handle pre_rhs_handle;
     int32_t pre_rhs_src_col, pre_rhs_dst_aux_col;
@@ -416,13 +429,19 @@ int cmdg_ocean_reconcile_from_fast_to_slow(cmdg_handle slow, cmdg_handle fast,
  * right-hand side twice (increment = false for the barotropic forcing, increment = true for the
  * stage), tendency_from_slow_to_fast!, update!, the sub-steps with cummulate_fast_solution!,
  * reconcile_from_fast_to_slow!.  `slow` = CMDG_PHYSICS_OCEAN_SE01 with its hooks installed,
- * `fast` = CMDG_PHYSICS_BAROTROPIC_SE01 on the one-layer extrusion of the 2-D grid.
+ * `fast` = CMDG_PHYSICS_BAROTROPIC_SE01 on the one-layer extrusion of the 2-D grid, created on
+ * the same device (CMDG_ERR_INVALID otherwise).
  * numImplSteps > 0 (implicit vertical diffusion, IVDCModel.jl) is not carried. */
 typedef struct cmdg_ocean01_desc {
     int32_t nvertelem;          /* stack size of the slow grid */
     double H;                   /* problem.H */
     const double *Imat;         /* HOST (Nq, Nq) column-major vertical grid.Imat of the slow grid */
     int32_t add_fast_substeps;  /* OceanModel.add_fast_substeps */
+    /* the fast solver's own LSRK scheme (split.fast_solver, SplitExplicitLSRK2nMethod.jl:150-165):
+     * nstages_fast > 0 with its three HOST coefficient arrays; 0 = the slow solver's scheme (the
+     * reference's simple_box_2dt.jl builds both solvers from LSRK54CarpenterKennedy) */
+    int32_t nstages_fast;
+    const double *rka_fast, *rkb_fast, *rkc_fast;
 } cmdg_ocean01_desc;
 int cmdg_split_explicit01_step(cmdg_handle slow, cmdg_handle fast, const cmdg_ocean01_desc *d,
                                double *Q3, double *dQ3, double *dQ2fast, double *Q2, double *dQ2,
