@@ -332,7 +332,8 @@ def kernel_source_digest():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "climatemachine.jl_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".h", ".hip")) or name == "Makefile":
+        # what the pass kernels are compiled from: the kernels, the laws, the flags
+        if name in ("kernels.h", "cmdg_common.h", "Makefile") or name.startswith("physics_"):
             h.update(name.encode())
             h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
@@ -426,8 +427,14 @@ def measure(cm, args, workload_args, rank, world, distributed, dev, with_halo):
     if rank == 0:
         dofs = total_elems * grid.Np * law.ns * 5 * args.steps
         kern = {}
+        ext = {}
         for k in ("GRADIENTS", "DIVGRAD", "GRADLAP", "TENDENCY", "PACK", "UNPACK", "FILTER"):
             ms, n = dg.profile_get(k)
+            if k + "_EXT" in cm._lib.CMDG_K:          # interior + exterior launches of the pass
+                ms_e, n_e = dg.profile_get(k + "_EXT")
+                if n_e:
+                    ext[k] = {"interior_avg_ms": ms / max(n, 1), "exterior_avg_ms": ms_e / n_e}
+                ms, n = ms + ms_e, n + n_e
             if n:
                 kern[k] = (ms / n, n)
         out = {"value": dofs / el, "ms_per_step": 1e3 * el / args.steps, "config": desc,
@@ -452,6 +459,7 @@ def measure(cm, args, workload_args, rank, world, distributed, dev, with_halo):
                     halo[name + "_avg_us"] = 1e3 * ms / n
                     halo[name + "_ms_per_step"] = ms / args.steps
                     halo["exchanges_per_step"] = n / args.steps
+            halo["passes"] = ext
             out["halo"] = halo
         passes = [k for k in kern if k in ("GRADIENTS", "DIVGRAD", "GRADLAP", "TENDENCY")]
         if passes:
@@ -666,17 +674,20 @@ def main(argv=None):
         log("[parity] %s" % json.dumps(parity))
 
     hs = args.workload == "heldsuarez"
-    both = hs and world > 1 and args.scaling == "both" and not args.nhorz
+    # BENCH_REHEARSE_NRANK=1: take the N > 1 path (both families, the one-GPU reference, the CPU
+    # barrier) with whatever world size this is -- a one-rank rehearsal on a single-GPU box
+    multi = world > 1 or bool(os.environ.get("BENCH_REHEARSE_NRANK"))
+    both = hs and multi and args.scaling == "both" and not args.nhorz
     head_scaling = "strong" if (hs and args.scaling in ("both", "strong")) else (
         args.scaling if hs else "weak")
     main_args = with_scaling(args, "strong" if head_scaling == "strong" else args.scaling)
     res = measure(cm, args, main_args, rank, world, distributed, dev,
-                  with_halo=world > 1 or bool(os.environ.get("BENCH_HALO_BLOCK")))
+                  with_halo=multi or bool(os.environ.get("BENCH_HALO_BLOCK")))
     sec = None
     if both and not args.no_secondary:
         sec = measure(cm, args, with_scaling(args, "weak"), rank, world, distributed, dev, with_halo=True)
     n1 = None
-    if world > 1 and hs and not args.no_n1_reference and not args.nhorz:
+    if multi and distributed and hs and not args.no_n1_reference and not args.nhorz:
         # the one-GPU value both families are scaled against, measured by rank 0 alone on its GPU
         # while the others wait (CPU barrier): the 43 200-element sphere of BASELINE configs[2]
         if rank == 0:

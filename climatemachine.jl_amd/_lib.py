@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMDG_LIB", os.path.join(_HERE, "libcmdg.so"))   # CMDG_LIB: tuning builds
 
 CMDG_K = dict(GRADIENTS=0, DIVGRAD=1, GRADLAP=2, TENDENCY=3, PACK=4, UNPACK=5, UPDATE_AUX=6,
-              FILTER=7, STACK_INTEGRAL=8, TRANSPORT=9, HALO_EXPOSED=10)
+              FILTER=7, STACK_INTEGRAL=8, TRANSPORT=9, HALO_EXPOSED=10, GRADIENTS_EXT=11,
+              DIVGRAD_EXT=12, GRADLAP_EXT=13, TENDENCY_EXT=14)
 STACK_MAXOUT = 8
 OPT_KEEP_GRADFLUX = 1
 OPT_STACK_HEIGHT = 2

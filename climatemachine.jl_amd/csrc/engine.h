@@ -337,7 +337,7 @@ struct EngineT : EngineBase {
     {
         if (n <= 0) return;
         Range range_(exterior ? "cmdg:gradients:exterior" : "cmdg:gradients");
-        prof_begin(CMDG_K_GRADIENTS, st);
+        prof_begin(exterior ? CMDG_K_GRADIENTS_EXT : CMDG_K_GRADIENTS, st);
         PassArgs<P> args = make_args(c, elems, n, diffusion_direction);
         args.h = halo_dev(exterior, gf_live() ? slot[SLOT_GF].sendbuf : nullptr,
                           ngl > 0 ? slot[SLOT_HG].sendbuf : nullptr);
@@ -353,7 +353,7 @@ struct EngineT : EngineBase {
     {
         if (n <= 0) return;
         Range range_(exterior ? "cmdg:divgrad:exterior" : "cmdg:divgrad");
-        prof_begin(CMDG_K_DIVGRAD, st);
+        prof_begin(exterior ? CMDG_K_DIVGRAD_EXT : CMDG_K_DIVGRAD, st);
         PassArgs<P> args = make_args(c, elems, n, diffusion_direction);
         args.h = halo_dev(exterior, slot[SLOT_HD].sendbuf, nullptr);
         hipLaunchKernelGGL((k_divgrad<P, NQ_, NQV_>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0, st,
@@ -364,7 +364,7 @@ struct EngineT : EngineBase {
     {
         if (n <= 0) return;
         Range range_(exterior ? "cmdg:gradlap:exterior" : "cmdg:gradlap");
-        prof_begin(CMDG_K_GRADLAP, st);
+        prof_begin(exterior ? CMDG_K_GRADLAP_EXT : CMDG_K_GRADLAP, st);
         PassArgs<P> args = make_args(c, elems, n, diffusion_direction);
         args.h = halo_dev(exterior, slot[SLOT_HG].sendbuf, nullptr);
         hipLaunchKernelGGL((k_gradlap<P, NQ_, NQV_>), dim3((unsigned)n), dim3(KDims<NQ_, NQV_>::NT), 0, st,
@@ -375,7 +375,7 @@ struct EngineT : EngineBase {
     {
         if (n <= 0) return;
         Range range_(exterior ? "cmdg:tendency:exterior" : "cmdg:tendency");
-        prof_begin(CMDG_K_TENDENCY, st);
+        prof_begin(exterior ? CMDG_K_TENDENCY_EXT : CMDG_K_TENDENCY, st);
 #ifdef CMDG_GF_ALWAYS
         const bool gfl = true;
 #else

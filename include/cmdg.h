@@ -498,7 +498,11 @@ enum {
     /* halo: the transport between pack and unpack (RCCL group or device copies) on the halo
      * stream, and the time the compute stream had to wait for an exchange to finish (the part of
      * an exchange NOT hidden behind interior work; one record per exchange, zero when hidden) */
-    CMDG_K_TRANSPORT = 9, CMDG_K_HALO_EXPOSED = 10, CMDG_K_COUNT = 11
+    CMDG_K_TRANSPORT = 9, CMDG_K_HALO_EXPOSED = 10,
+    /* the exterior launches of the four passes of a handle with neighbours (their interior
+     * launches stay under CMDG_K_GRADIENTS ... CMDG_K_TENDENCY) */
+    CMDG_K_GRADIENTS_EXT = 11, CMDG_K_DIVGRAD_EXT = 12, CMDG_K_GRADLAP_EXT = 13,
+    CMDG_K_TENDENCY_EXT = 14, CMDG_K_COUNT = 15
 };
 /* bracket every launch with HIP events on the launch stream (off by default) */
 int cmdg_profile_enable(cmdg_handle h, int32_t on);

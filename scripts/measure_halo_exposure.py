@@ -94,7 +94,8 @@ def main():
            "exchange": modes,
            "ms_per_step": 1e3 * el / args.steps, "steps": args.steps,
            "ms_per_step_runs": [1e3 * r / args.steps for r in runs], "kernels": {}}
-    for k in ("GRADIENTS", "DIVGRAD", "GRADLAP", "TENDENCY", "PACK", "TRANSPORT", "UNPACK", "HALO_EXPOSED"):
+    for k in ("GRADIENTS", "GRADIENTS_EXT", "DIVGRAD", "DIVGRAD_EXT", "GRADLAP", "GRADLAP_EXT", "TENDENCY",
+              "TENDENCY_EXT", "PACK", "TRANSPORT", "UNPACK", "HALO_EXPOSED"):
         ms, n = dg.profile_get(k)
         if n:
             out["kernels"][k] = {"avg_us": 1e3 * ms / n, "launches": n, "total_ms_per_step": ms / args.steps}

@@ -30,3 +30,17 @@ def torch():
     import torch as t
     assert t.cuda.is_available(), "no HIP device: the product path has no CPU fallback"
     return t
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Observed maxima of the comparisons whose tolerance is looser than 1e-12 (helpers.observe)."""
+    try:
+        import json
+        from helpers import OBSERVED
+        if OBSERVED:
+            out = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, "observed_maxima.json"), "w") as f:
+                json.dump(dict(sorted(OBSERVED.items())), f, indent=1)
+    except Exception:
+        pass

@@ -578,3 +578,16 @@ def periodic_hyperdiffusion_dim2_setup(Ne=4, N=4, direction=0):
     dt = dx ** 4 / 25 / D.sum()
     dt = 1.0 / np.ceil(1.0 / dt)
     return law, grid, dt, np.sqrt(Ly)
+
+
+OBSERVED = {}
+
+
+def observe(name, value):
+    """Records the largest value seen under ``name`` (written to gpurun_out/observed_maxima.json
+    at the end of the session, tests/conftest.py) and returns it: for tolerances looser than the
+    north star's 1e-12, so that what the device actually reaches stands next to the bound."""
+    v = float(value)
+    if not (OBSERVED.get(name, -1.0) >= v):
+        OBSERVED[name] = v
+    return value

@@ -4,6 +4,11 @@ density-current number (density_current_model.jl:247) end to end on the device. 
 import numpy as np
 import pytest
 
+# Tolerances: the north star's 1e-12 throughout.  Round 2 used 1e-11 on the argument that exp / pow /
+# log differ between the device's libm and the host's; the maxima the device actually reaches are
+# recorded by helpers.observe (profiles/r03_observed_maxima.json): 2.1e-13 at worst (gradient flux of a
+# cloudy state), 3.6e-14 / 9.1e-14 for the cloudy tendency / two LSRK steps, <= 8e-16 unsaturated.
+from helpers import observe  # noqa: E402
 from helpers import density_current_setup, rel_linf, rising_bubble_setup
 from test_moist_oracle import moist_twin_of_bubble
 
@@ -54,16 +59,16 @@ def test_moist_tendency_and_aux_match_oracle(cm, oracle, torch, closure):
         dg(Tg, _gpu(torch, Q0), 0.0, alpha, beta)
         Tn = Tg.cpu().numpy()
         for s in range(6):
-            assert rel_linf(Tn[:, s], To[:, s]) < 1e-11, s
+            assert observe("moist:1 rel_linf_Tn_s_To_s_", rel_linf(Tn[:, s], To[:, s])) < 1e-12, s
         gfg = dg.state_gradient_flux.cpu().numpy()
         for s in range(law.ngradflux):
             sc = max(np.abs(odg.state_gradient_flux[:, s]).max(), 1e-300)
-            assert np.abs(gfg[:, s] - odg.state_gradient_flux[:, s]).max() / sc < 1e-11, s
+            assert observe("moist:6 scaled_abs", np.abs(gfg[:, s] - odg.state_gradient_flux[:, s]).max() / sc) < 1e-12, s
     auxg = dg.state_auxiliary.cpu().numpy()
     assert odg.state_auxiliary[:, 17].max() > 1e-4                # cloudy: q_liq
     for c in (15, 16, 17, 18):
         sc = max(np.abs(odg.state_auxiliary[:, c]).max(), 1e-300)
-        assert np.abs(auxg[:, c] - odg.state_auxiliary[:, c]).max() / sc < 1e-11, c
+        assert observe("moist:7 scaled_abs", np.abs(auxg[:, c] - odg.state_auxiliary[:, c]).max() / sc) < 1e-12, c
     Qo, dQo = Q0.copy(), np.zeros_like(Q0)
     for i in range(2):
         oracle.lsrk54_step(odg, Qo, dQo, i * 0.02, 0.02)
@@ -72,7 +77,7 @@ def test_moist_tendency_and_aux_match_oracle(cm, oracle, torch, closure):
     dg.lsrk_run(Q, dQ, 0.0, 0.02, 2, oracle.RKA, oracle.RKB, oracle.RKC)
     dg.synchronize()
     for s in range(6):
-        assert rel_linf(Q.cpu().numpy()[:, s], Qo[:, s]) < 1e-11, s
+        assert observe("moist:2 rel_linf_Q_cpu_numpy_s_Qo_s_", rel_linf(Q.cpu().numpy()[:, s], Qo[:, s])) < 1e-12, s
     dg.close()
 
 
@@ -103,7 +108,7 @@ def test_moist_order_six_matches_oracle(cm, oracle, torch):
     Tg = _gpu(torch, np.zeros_like(Q0))
     dg(Tg, _gpu(torch, Q0), 0.0, 1.0, 0.0)
     for s in range(6):
-        assert rel_linf(Tg.cpu().numpy()[:, s], To[:, s]) < 1e-11, s
+        assert observe("moist:3 rel_linf_Tg_cpu_numpy_s_To_s_", rel_linf(Tg.cpu().numpy()[:, s], To[:, s])) < 1e-12, s
     dg.close()
 
 
@@ -142,7 +147,7 @@ def test_bomex_tendency_and_steps_match_oracle(cm, oracle, torch, N):
     Tn = Tg.cpu().numpy()
     assert odg.state_auxiliary[:, 17].max() > 1e-5
     for s in range(6):
-        assert rel_linf(Tn[:, s], To[:, s]) < 1e-11, s
+        assert observe("moist:4 rel_linf_Tn_s_To_s_", rel_linf(Tn[:, s], To[:, s])) < 1e-12, s
     Qo, dQo = Q0.copy(), np.zeros_like(Q0)
     for i in range(2):
         oracle.lsrk54_step(odg, Qo, dQo, i * 0.05, 0.05)
@@ -151,7 +156,7 @@ def test_bomex_tendency_and_steps_match_oracle(cm, oracle, torch, N):
     dg.lsrk_run(Q, dQ, 0.0, 0.05, 2, oracle.RKA, oracle.RKB, oracle.RKC)
     dg.synchronize()
     for s in range(6):
-        assert rel_linf(Q.cpu().numpy()[:, s], Qo[:, s]) < 1e-11, s
+        assert observe("moist:5 rel_linf_Q_cpu_numpy_s_Qo_s_", rel_linf(Q.cpu().numpy()[:, s], Qo[:, s])) < 1e-12, s
     dg.close()
 
 
@@ -197,7 +202,7 @@ def test_bomex_local_multirank_matches_single_rank(cm, torch):
         for i, g in enumerate(gr.topology.globalelems[:gr.nreal]):
             for s in range(6):
                 sc = max(np.abs(ref[int(g)][s]).max(), 1e-6)
-                assert np.abs(qn[i, s] - ref[int(g)][s]).max() / sc < 1e-11, (s, i)
+                assert observe("moist:8 scaled_abs", np.abs(qn[i, s] - ref[int(g)][s]).max() / sc) < 1e-12, (s, i)
     for d in dgs + [dg1]:
         d.close()
 
