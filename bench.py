@@ -737,24 +737,27 @@ def main(argv=None):
         dist.destroy_process_group()
 
 
-def ocean_setup(cm, Nx, Nz):
+def ocean_setup(cm, Nx, Nz, rank=0, size=1, connectivity=None):
     """BASELINE configs[4]: hydrostatic Boussinesq ocean box with the split-explicit stepper
     (test/Ocean/SplitExplicit/hydrostatic_spindown.jl:3-140, SplitExplicitSolver variant:
     SimpleBox 1e6 x 1e6 x 400 m, 3-D HBModel + 2-D ShallowWaterModel on the one-layer extrusion
-    of the horizontal grid, periodic in x and y) at Nx x Nx x Nz elements, N = 4."""
+    of the horizontal grid, periodic in x and y) at Nx x Nx x Nz elements per rank, N = 4; more
+    ranks extend the box in y (same element size), both grids partitioned alike (whole columns)."""
     O, M = cm.ocean, cm.mesh
-    Lx, Ly, H = 1e6, 1e6, 400.0
+    Lx, Ly, H = 1e6, 1e6 * size, 400.0
     problem = O.SimpleBox(Lx, Ly, H, rotation=O.FIXED)
     law3 = O.HydrostaticBoussinesqModel(problem, c_h=1.0, alpha_T=0.0, kappa_h=0.0, kappa_z=0.0,
                                         coupled=True)
     law2 = O.ShallowWaterModel(problem, law3.nu_h, advection=False, coupled=True, c=1.0)
-    x, y = np.linspace(0.0, Lx, Nx + 1), np.linspace(0.0, Ly, Nx + 1)
+    x, y = np.linspace(0.0, Lx, Nx + 1), np.linspace(0.0, Ly, Nx * size + 1)
     topl = M.StackedBrickTopology([x, y, np.linspace(-H, 0.0, Nz + 1)],
                                   periodicity=(True, True, False),
-                                  boundary=((0, 0), (0, 0), (1, 2)))
+                                  boundary=((0, 0), (0, 0), (1, 2)), rank=rank, size=size,
+                                  **({"connectivity": connectivity} if connectivity else {}))
     grid3 = M.DiscontinuousSpectralElementGrid(topl, 4)
     # (fields are constant along the extrusion: two nodes carry them, 50 nodes per element)
-    grid2 = O.extruded_barotropic_grid(x, y, 4, N_extrusion=1)
+    grid2 = O.extruded_barotropic_grid(x, y, 4, N_extrusion=1, rank=rank, size=size,
+                                       **({"connectivity": connectivity} if connectivity else {}))
     # the reference's 5 x 5 x 8 runs use dt_slow = 5400 s over dt_fast = 300 s; both scale with
     # the horizontal element size so that the finer box stays inside the barotropic CFL limit
     return law3, grid3, law2, grid2, 5400.0 * 5.0 / Nx, 300.0 * 5.0 / Nx
@@ -764,31 +767,59 @@ def main_ocean(args, rank, world, local):
     """``--workload ocean-split-explicit``: one "step" is one slow LSRK54 step of the 3-D model
     (5 stages, each with its barotropic sub-steps, the two slow right-hand sides and the
     exchanges between the models).  ``value`` counts the 3-D model's DOF updates."""
-    if world != 1:
-        raise SystemExit("ocean-split-explicit: one GPU (the partitioned split-explicit stepper is "
-                         "covered by the local-transport tests, not by this bench line)")
     import torch
+    import torch.distributed as dist
     from cmdg_loader import cm
     torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
     O = cm.ocean
     Nx, Nz = args.ocean_nx, args.ocean_nz
     t0 = time.time()
-    law3, g3, law2, g2, dt_slow, dt_fast = ocean_setup(cm, Nx, Nz)
-    log("[ocean] grids: %.1f s" % (time.time() - t0))
-    dg3 = cm.dgmodel.DGModel(law3, g3)
+    law3, g3, law2, g2, dt_slow, dt_fast = ocean_setup(cm, Nx, Nz, rank, world)
+    log("[ocean rank %d] grids: %d + %d ghost 3-D elements, %.1f s" % (
+        rank, g3.nreal, g3.nelem - g3.nreal, time.time() - t0))
+    dg3 = cm.dgmodel.DGModel(law3, g3, device=dev)
     keep = O.install_hydrostatic_boussinesq_hooks(dg3)
-    dg2 = cm.dgmodel.DGModel(law2, g2,
+    dg2 = cm.dgmodel.DGModel(law2, g2, device=dev,
                              numerical_flux_first_order=cm.balancelaws.CentralNumericalFluxFirstOrder)
+    if distributed:        # one RCCL communicator per model: their exchanges interleave freely
+        for d in (dg3, dg2):
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(cm.dgmodel.rccl_unique_id()), dtype=torch.uint8).clone()
+            uid = uid.to(dev)
+            dist.broadcast(uid, 0)
+            d.comm_init_rccl(uid.cpu().numpy().tobytes(), rank, world)
+            d.comm_selftest()
+
+    def sync_all():
+        dg3.synchronize(), dg2.synchronize()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
     Q3, Q2 = dg3.init_ode_state(0.0), dg2.init_ode_state(0.0)
     se = O.SplitExplicitSolver(dg3, dg2, Q3, Q2, dt_slow, dt_fast)
     se.dostep(Q3, Q2, args.warmup)
-    dg3.synchronize(), dg2.synchronize()
-    torch.cuda.synchronize()
+    sync_all()
     t0 = time.perf_counter()
     se.dostep(Q3, Q2, args.steps)
     dg3.synchronize(), dg2.synchronize()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    total3 = g3.nreal
+    if distributed:
+        dist.barrier()
+        tt = torch.tensor([el, float(g3.nreal)], device=dev, dtype=torch.float64)
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        el, total3 = float(mx[0].item()), int(round(tt[1].item()))
     for d in (dg3, dg2):
         d.profile_reset()
         if not args.no_events:
@@ -804,7 +835,13 @@ def main_ocean(args, rank, world, local):
     nsub = sum(int(np.ceil(((1 - RKC[s]) if s == 4 else (RKC[s + 1] - RKC[s])) * dt_slow / dt_fast))
                for s in range(5))
     finite = bool(torch.isfinite(Q3[:g3.nreal]).all().item() and torch.isfinite(Q2[:g2.nreal]).all().item())
-    dofs = g3.nreal * g3.Np * law3.ns * 5 * args.steps
+    dofs = total3 * g3.Np * law3.ns * 5 * args.steps
+    if distributed and rank != 0:
+        del keep
+        dg3.close(), dg2.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     kernels = {}
     for name, d in (("slow", dg3), ("fast", dg2)):
         for kn in ("GRADIENTS", "TENDENCY", "FILTER", "STACK_INTEGRAL"):
@@ -813,16 +850,17 @@ def main_ocean(args, rank, world, local):
                 kernels["%s_%s" % (name, kn.lower())] = {
                     "avg_ms": ms / n, "launches_per_step": n / args.steps, "ms_per_step": ms / args.steps}
     out = {"metric": "DG RHS DOF-updates/sec", "value": dofs / el, "unit": "DOF-updates/s",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "hydrostatic Boussinesq ocean box (BASELINE configs[4]), split-explicit "
                                   "barotropic / baroclinic stepper, %dx%dx%d elements, N=4 (%d 3-D "
                                   "elements, %d columns), dt_slow=%g s, dt_fast<=%g s (%d barotropic "
                                   "LSRK54 steps per slow step), Coupled, fp64"
-                                  % (Nx, Nx, Nz, g3.nreal, g2.nreal, dt_slow, dt_fast, nsub),
-                      "elements": int(g3.nreal), "nodes_per_element": int(g3.Np), "states": law3.ns,
-                      "parallelism": "1 rank"},
+                                  % (Nx, Nx * world, Nz, total3, total3 // Nz, dt_slow, dt_fast, nsub),
+                      "elements": int(total3), "nodes_per_element": int(g3.Np), "states": law3.ns,
+                      "parallelism": "element partition (Hilbert, whole columns, both models alike), "
+                                     "%d rank(s), RCCL p2p halo" % world},
            "node_updates_per_s": dofs / el / law3.ns, "state_finite": finite, "kernels_ms": kernels}
     if "slow_tendency" in kernels:
         info = kernel_info(dg3, law3, g3, (0, 0))
@@ -838,7 +876,7 @@ def main_ocean(args, rank, world, local):
                            "algorithmic_bytes_per_node": needed, "avg_launch_ms": avg_ms,
                            "timing": "HIP events on the launch stream, second pass of the same %d "
                                      "steps (%.3f ms/step with events)" % (args.steps, 1e3 * el_ev / args.steps)}
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:
         from oracle import oracle as OR
         OR.build()
         F = cm.mesh.filters
@@ -857,6 +895,9 @@ def main_ocean(args, rank, world, local):
     print(json.dumps(out), flush=True)
     del keep
     dg3.close(), dg2.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
     if not finite:
         raise SystemExit("bench.py: the state is not finite after the timed steps")
 

@@ -320,3 +320,43 @@ def test_full_size_ocean_box_properties(cm, torch):
         runs.append((Q3[:g3.nreal].clone(), Q2[:g2.nreal].clone()))
         _close(dg3, dg2, keep)
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
+def test_split_explicit_through_rccl_equals_device_copies(cm, torch):
+    """The partitioned split-explicit step as ``bench.py --workload ocean-split-explicit --gpus N``
+    runs it -- one (slow, fast) pair per process, each model with its own RCCL communicator --
+    rehearsed on one GPU: rank 0 of a 2-rank box with itself as every neighbour.  The ghost data
+    is then the rank's own, so the numbers mean nothing physically, but every exchange of both
+    models (Q and the gradient flux of the 3-D model with its hooks on the ghost stacks, Q and the
+    gradient flux of the barotropic model, direct and pipelined) goes through ncclSend / ncclRecv
+    groups, and must give what the same exchanges give through device copies, bit for bit."""
+    import bench
+    out = []
+    for transport in ("rccl", "local"):
+        law3, g3, law2, g2, dt_slow, dt_fast = bench.ocean_setup(cm, 4, 3, rank=0, size=2,
+                                                                  connectivity="face")
+        for g in (g3, g2):
+            nn = len(g.nabrtorank)
+            send = np.asarray(g.nabrtovmapsend).reshape(nn, 2)
+            recv = np.asarray(g.nabrtovmaprecv).reshape(nn, 2)
+            assert nn >= 1 and all(send[n][1] - send[n][0] == recv[n][1] - recv[n][0] for n in range(nn))
+            g.nabrtorank = [0] * nn
+        dg3, dg2, keep = _device_pair(cm, torch, law3, g3, law2, g2)
+        if transport == "rccl":
+            for d in (dg3, dg2):
+                d.comm_init_rccl(cm.dgmodel.rccl_unique_id(), 0, 1)
+        else:
+            cm.dgmodel.connect_local([dg3])
+            cm.dgmodel.connect_local([dg2])
+        Q3, Q2 = dg3.init_ode_state(0.0), dg2.init_ode_state(0.0)
+        se = cm.ocean.SplitExplicitSolver(dg3, dg2, Q3, Q2, dt_slow, dt_fast)
+        if transport == "rccl":
+            se.dostep(Q3, Q2, 2)
+        else:
+            cm.ocean.SplitExplicitSolver.group_dostep([se], [Q3], [Q2], 2)
+        assert dg2.query("DIRECT_SEND") == 1 and dg2.query("HALO_PIPELINE") == 1
+        assert dg3.query("DIRECT_SEND") == 1 and dg3.query("DIRECT_RECV") == 0      # hooks: unpacked
+        out.append((Q3[:g3.nreal].clone(), Q2[:g2.nreal].clone()))
+        assert torch.isfinite(out[-1][0]).all() and torch.isfinite(out[-1][1]).all()
+        _close(dg3, dg2, keep)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
