@@ -1472,6 +1472,7 @@ int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value)
     case CMDG_OPT_HALO_PIPELINE:
         if (int r = e->synchronize()) return set_err(h, r);
         e->no_pipeline = value == 0;
+        e->invalidate_sends();
         return CMDG_OK;
     default: return set_err(h, e->fail(CMDG_ERR_INVALID, "cmdg_set_option: unknown option"));
     }
@@ -1510,6 +1511,7 @@ int cmdg_halo_begin(cmdg_handle h, double *array, int32_t nstate)
 {
     if (!h || !array) return CMDG_ERR_INVALID;
     DevGuard guard_(h->eng);
+    h->eng->invalidate_sends();  // the caller's array: always packed
     return set_err(h, h->eng->halo_begin(SLOT_Q, array, nstate));
 }
 int cmdg_halo_end(cmdg_handle h, double *array, int32_t nstate)
@@ -1655,6 +1657,7 @@ int cmdg_group_halo(cmdg_handle *handles, int32_t n, double **arrays, int32_t ns
     for (int i = 0; i < n; ++i)
         if (!handles[i] || !arrays[i]) return CMDG_ERR_INVALID;
     DevGuard guard_(handles[0]->eng);
+    for (int i = 0; i < n; ++i) handles[i]->eng->invalidate_sends();
     for (int i = 0; i < n; ++i)
         if (int r = handles[i]->eng->halo_begin(SLOT_Q, arrays[i], nstate)) return set_err(handles[i], r);
     for (int i = 0; i < n; ++i)
@@ -1782,6 +1785,9 @@ int cmdg_set_filters(cmdg_handle h, cmdg_filter gradient_filter, cmdg_filter ten
     for (FilterObj *o : {gfl, tfl})
         if (o && o->target != CMDG_TARGET_INDICES)
             return set_err(h, e->fail(CMDG_ERR_INVALID, "gradient/tendency filters take FilterIndices targets"));
+    // filters decide which streams the next evaluation's launches go to: start it from a clean slate
+    if (int r = e->synchronize()) return set_err(h, r);
+    e->invalidate_sends();
     e->gradient_filter = gfl;
     e->tendency_filter = tfl;
     e->step_filter = reinterpret_cast<FilterObj *>(step_filter);
@@ -1792,6 +1798,8 @@ int cmdg_set_rhs_hooks(cmdg_handle h, const cmdg_rhs_hooks *hooks)
 {
     if (!h) return CMDG_ERR_INVALID;
     DevGuard guard_(h->eng);
+    if (int r = h->eng->synchronize()) return set_err(h, r);  // (hooks change the stream layout too)
+    h->eng->invalidate_sends();
     return set_err(h, h->eng->set_hooks(hooks));
 }
 

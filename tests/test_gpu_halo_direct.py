@@ -176,3 +176,47 @@ def test_direct_exchange_through_rccl(cm, torch):
     assert np.array_equal(out[0], out[1])
     assert counts[0]["PACK"] == 1, counts
     assert counts[1]["PACK"] == counts[1]["UNPACK"] > 1
+
+
+def test_switching_between_one_stream_and_two_pipelines(cm, torch):
+    """A gradient filter puts a partitioned handle on the reference's one-stream order (its exterior
+    gradient launch leaves the gradient flux unfiltered in the send buffer, so that one is packed);
+    taking the filter away switches to the two pipelines.  Steps with, without and again with the
+    filter, two ranks: direct exchange == reference exchange bit for bit across the switches."""
+    from helpers import pseudo1d_setup
+    F = cm.mesh.filters
+    out = []
+    for reference in (False, True):
+        dgs, Qs, grids, filts = [], [], [], []
+        for r in range(2):
+            law, grid, dt = pseudo1d_setup(direction=0, rank=r, size=2)
+            dg = cm.dgmodel.DGModel(law, grid, direction=0)
+            if reference:
+                dg.set_option(cm._lib.OPT_REFERENCE_HALO, 1)
+            q = dg.init_ode_state(0.0)
+            q[grid.nreal:] = float("nan")
+            filts.append(F.make_device_filter(dg, F.CutoffFilter(grid, 3),
+                                              F.FilterIndices(range(1, law.ngradflux + 1)),
+                                              nstate=law.ngradflux))
+            dgs.append(dg), Qs.append(q), grids.append(grid)
+        dQs = [x.create_state() for x in dgs]
+        torch.cuda.synchronize()
+        cm.dgmodel.connect_local(dgs)
+        s = cm.odesolvers.LSRK54CarpenterKennedy(dgs[0], Qs[0], dt=dt)
+        t = 0.0
+        for filtered in (True, False, True, False):
+            for dg, f in zip(dgs, filts):
+                dg.set_filters(gradient_filter=f if filtered else None)
+            assert dgs[0].query("HALO_PIPELINE") == (0 if filtered or reference else 1)
+            cm.dgmodel.group_lsrk_run(dgs, Qs, dQs, t, dt, 2, s.RKA, s.RKB, s.RKC)
+            t += 2 * dt
+        for x in dgs:
+            x.synchronize()
+        out.append([q[:g.nreal].cpu().numpy().copy() for q, g in zip(Qs, grids)])
+        for dg, f in zip(dgs, filts):
+            dg.set_filters()
+            f.close()
+            dg.close()
+    for a, b in zip(*out):
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b)
