@@ -14,6 +14,15 @@
  *   elemtobndy (nface, nelem) Int64                           [Topologies.jl]
  * "device" pointers must stay valid from cmdg_create to cmdg_destroy.
  * Every function returns 0 (CMDG_OK) or a negative cmdg_status; none throws.
+ *
+ * Environment (read when a handle is created; none is needed in normal use):
+ *   CMDG_RCCL_LIB          path of the RCCL library to use (default: the one already in the process,
+ *                          e.g. torch's, else librccl.so.1)
+ *   CMDG_ROCTX=1           load the roctx library so that the phases of an evaluation carry ranges
+ *                          (cmdg:halo:pack / transport / end, cmdg:<pass>[:exterior]); they are
+ *                          emitted anyway when rocprofv3 --marker-trace has loaded it
+ *   CMDG_REFERENCE_HALO=1, CMDG_HALO_PIPELINE=0   initial values of the two exchange options below
+ *   CMDG_HALO_PRIORITY=1   create the halo stream with the highest stream priority
  */
 #ifndef CMDG_H
 #define CMDG_H
