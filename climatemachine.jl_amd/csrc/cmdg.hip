@@ -2,6 +2,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -136,6 +137,13 @@ EngineBase::~EngineBase()
     if (d_Dv) hipFree(d_Dv);
     if (ev_comp) hipEventDestroy(ev_comp);
     if (prof_ext_done) hipEventDestroy(prof_ext_done);
+    if (graph_exec) hipGraphExecDestroy(graph_exec);
+    if (d_gtime) hipFree(d_gtime);
+    if (gev_fork) hipEventDestroy(gev_fork);
+    for (int i = 0; i < NGEV; ++i) {
+        if (gev_int[i]) hipEventDestroy(gev_int[i]);
+        if (gev_ext[i]) hipEventDestroy(gev_ext[i]);
+    }
     for (int i = 0; i < 2; ++i) {
         if (ev_int[i]) hipEventDestroy(ev_int[i]);
         if (ev_ext[i]) hipEventDestroy(ev_ext[i]);
@@ -214,6 +222,8 @@ int EngineBase::init(const cmdg_desc *d)
         HIPCHK(hipEventCreateWithFlags(&ev_int[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_ext[i], hipEventDisableTiming));
     }
+    HIPCHK(hipEventCreateWithFlags(&gev_fork, hipEventDisableTiming));
+    if (const char *v = getenv("CMDG_STEP_GRAPH")) step_graph = *v && *v != '0';
     HIPCHK(hipEventCreateWithFlags(&ev_comp, hipEventDisableTiming));
     HIPCHK(hipMalloc(&d_D, sizeof(double) * NQ * NQ));
     HIPCHK(hipMemcpy(d_D, d->D, sizeof(double) * NQ * NQ, hipMemcpyHostToDevice));
@@ -435,6 +445,8 @@ int EngineBase::halo_pack(int s, double *array, int nvar, int ncol, bool on_halo
     h.fresh_for = nullptr;
     // the data to send is produced on the compute stream -- unless an exterior launch of the
     // halo stream's own pipeline wrote it (pipelined())
+    if (capturing && !(fresh && on_halo_stream))
+        return fail(CMDG_ERR_UNSUPPORTED, "step graph: an exchange of this step would have to be packed");
     if (!(fresh && on_halo_stream)) {
         HIPCHK(hipEventRecord(ev_comp, s_comp));
         HIPCHK(hipStreamWaitEvent(s_comm, ev_comp, 0));
@@ -450,7 +462,7 @@ int EngineBase::halo_pack(int s, double *array, int nvar, int ncol, bool on_halo
                            h.sendbuf, array, d_vmapsend, nvmapsend, Np, nvar, ncol);
         prof_end(s_comm);
     }
-    HIPCHK(hipEventRecord(h.ev_packed, s_comm));
+    if (!capturing) HIPCHK(hipEventRecord(h.ev_packed, s_comm));  // (read by the local transport only)
     return CMDG_OK;
 }
 
@@ -458,6 +470,17 @@ int EngineBase::halo_post(const int *slots, int nslots)
 {
     if (!communicate()) return CMDG_OK;
     Range range_("cmdg:halo:transport");
+    const auto host_t0 = std::chrono::steady_clock::now();
+    struct HostTimer {  // host time spent posting exchanges (cmdg_query CMDG_Q_HOST_POST_NS)
+        EngineBase *e;
+        std::chrono::steady_clock::time_point t0;
+        ~HostTimer()
+        {
+            e->host_post_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(
+                                   std::chrono::steady_clock::now() - t0).count();
+            e->host_post_n += 1;
+        }
+    } host_timer_{this, host_t0};
     if (transport == TRANSPORT_RCCL) {
         // one group for everything that begins here: every neighbour pair has its own xGMI
         // link, and one group costs one RCCL launch however many arrays travel
@@ -605,9 +628,16 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
 #define TRY(x) \
     if ((r = (x)) != CMDG_OK) return r
     // interior launch I_p of a pass (enqueued before its exterior launch): waits for E_(p-1)
+    // a capture has events of its own (the eager ones keep their last eager record), and its first
+    // launches wait for nothing of the step before: graphs launched on one stream run in order
+    hipEvent_t *const EI = capturing ? gev_int : ev_int, *const EE = capturing ? gev_ext : ev_ext;
+    // index of pass q's event: alternating parity when eager, one event per pass in a capture
+    auto evi = [&](int64_t q) { return capturing ? (int)((cap_pass + (q - pass_seq)) % NGEV) : (int)(q & 1); };
     auto interior_begin = [&]() -> int {
         ++pass_seq;
+        if (capturing) ++cap_pass;
         if (!pipe) return CMDG_OK;
+        if (capturing && cap_interior++ == 0) return CMDG_OK;
         if (profiling && prof_ext_done) {
             // exposed: the compute stream idle until the previous exterior launch is done
             ProfRec pr;
@@ -619,20 +649,21 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
             prof_ext_done = nullptr;
             prof.push_back(pr);
         }
-        HIPCHK(hipStreamWaitEvent(s_comp, ev_ext[(pass_seq - 1) & 1], 0));
+        HIPCHK(hipStreamWaitEvent(s_comp, EE[evi(pass_seq - 1)], 0));
         return CMDG_OK;
     };
     auto interior_end = [&]() -> int {
-        if (pipe) HIPCHK(hipEventRecord(ev_int[pass_seq & 1], s_comp));
+        if (pipe) HIPCHK(hipEventRecord(EI[evi(pass_seq)], s_comp));
         return CMDG_OK;
     };
     // exterior launch E_p: waits for I_(p-1)
     auto exterior_begin = [&]() -> int {
-        if (pipe) HIPCHK(hipStreamWaitEvent(s_comm, ev_int[(pass_seq - 1) & 1], 0));
+        if (pipe && !(capturing && cap_exterior++ == 0))
+            HIPCHK(hipStreamWaitEvent(s_comm, EI[evi(pass_seq - 1)], 0));
         return CMDG_OK;
     };
     auto exterior_end = [&]() -> int {
-        if (pipe) HIPCHK(hipEventRecord(ev_ext[pass_seq & 1], s_comm));
+        if (pipe) HIPCHK(hipEventRecord(EE[evi(pass_seq)], s_comm));
         if (pipe && profiling) {
             if (prof_ext_done) hipEventDestroy(prof_ext_done);
             hipEventCreate(&prof_ext_done);
@@ -742,7 +773,7 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
         if (dsend && c.lsrk) mark_fresh(SLOT_Q, c.Qout, ns);
         // whatever follows on the compute stream (a filter, the caller's next call, the next
         // evaluation's first interior launch) finds this evaluation complete
-        if (pipe) HIPCHK(hipStreamWaitEvent(s_comp, ev_ext[pass_seq & 1], 0));
+        if (pipe) HIPCHK(hipStreamWaitEvent(s_comp, EE[evi(pass_seq)], 0));
         if (tendency_filter) TRY(filter_apply(tendency_filter, c.tendency, ns));  // (:417-425)
         if (c.update_after) {
             const int64_t n = (int64_t)Np * ns * nreal;
@@ -808,7 +839,7 @@ int group_rhs(std::vector<EngineBase *> &g, std::vector<RhsCtx> &c, bool keep_fr
 // continued: this step follows the previous step of the same run with nothing in between
 int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, double t, double dt,
                     int nstages, const double *rka, const double *rkb, const double *rkc,
-                    bool continued)
+                    bool continued, const double *stage_times_dev)
 {
     if (nstages < 1) return g[0]->fail(CMDG_ERR_INVALID, "lsrk: nstages < 1");
     for (auto *e : g)
@@ -828,6 +859,7 @@ int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, doubl
             }
             x.tendency = dQ[i];
             x.t = t + rkc[s] * dt;
+            x.tptr = stage_times_dev ? stage_times_dev + s : nullptr;
             x.alpha = 1.0;  // rhs!(dQ, Q, p, time + RKC[s] * dt, increment = true)
             x.beta = 1.0;
             x.lsrk = fused;
@@ -849,6 +881,130 @@ int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, doubl
             e->invalidate_sends();
         }
     }
+    return CMDG_OK;
+}
+
+// ---- cmdg_lsrk_run: eager steps, or one captured step replayed (EngineBase::step_graph) -----
+namespace {
+struct StepTimesInit {
+    double t_next, dt;
+    int nstages;
+    double rkc[16];
+};
+// [t_next, dt, times[16], rkc[16]] <- the values of a run
+__global__ void k_step_times_init(double *g, StepTimesInit v)
+{
+    g[0] = v.t_next;
+    g[1] = v.dt;
+    for (int s = 0; s < v.nstages; ++s) g[18 + s] = v.rkc[s];
+}
+// head of the captured step: the stage times of this step, then t += dt (updatetime!)
+__global__ void k_step_times(double *g, int nstages)
+{
+    const double t = g[0], dt = g[1];
+    for (int s = 0; s < nstages; ++s) g[2 + s] = t + g[18 + s] * dt;
+    g[0] = t + dt;
+}
+}  // namespace
+
+bool EngineBase::graph_eligible() const
+{
+    const bool comm = communicate() && !(stacked && direction == DIR_VERTICAL);
+    // Handles that exchange stay eager: with ncclSend / ncclRecv groups recorded on the halo stream
+    // (RCCL 2.26.6, ROCm 7.0.2, a rank as its own neighbour) hipStreamEndCapture crashes; the same
+    // two-stream capture with device copies in place of the groups instantiates and replays.
+    return step_graph && !graph_failed && !profiling && !step_filter && !tendency_filter &&
+           !gradient_filter && !has_hooks && (!has_update_aux() || fused_update_aux()) && !comm;
+}
+
+int EngineBase::capture_step(double *Q, double *dQ, double dt, int nstages, const double *rka,
+                             const double *rkb, const double *rkc)
+{
+    const bool comm = communicate() && !(stacked && direction == DIR_VERTICAL);
+    if (graph_exec) {
+        hipGraphExecDestroy(graph_exec);
+        graph_exec = nullptr;
+    }
+    if (!d_gtime) HIPCHK(hipMalloc(&d_gtime, sizeof(double) * 34));
+    std::vector<EngineBase *> one{this};
+    double *Qs[1] = {Q}, *dQs[1] = {dQ};
+    if (4 * nstages + 1 > NGEV) return fail(CMDG_ERR_UNSUPPORTED, "step graph: too many stages");
+    for (int i = 0; i < NGEV; ++i) {  // (created on first use: most handles never capture)
+        if (!gev_int[i]) HIPCHK(hipEventCreateWithFlags(&gev_int[i], hipEventDisableTiming));
+        if (!gev_ext[i]) HIPCHK(hipEventCreateWithFlags(&gev_ext[i], hipEventDisableTiming));
+    }
+    capturing = true;
+    cap_interior = cap_exterior = cap_pass = 0;
+    hipGraph_t graph = nullptr;
+    int r = CMDG_OK;
+    if (hipStreamBeginCapture(s_comp, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        capturing = false;
+        return fail(CMDG_ERR_HIP, "step graph: hipStreamBeginCapture failed");
+    }
+    hipLaunchKernelGGL(k_step_times, dim3(1), dim3(1), 0, s_comp, d_gtime, nstages);
+    if (comm) {  // the halo stream joins the capture
+        if (hipEventRecord(gev_fork, s_comp) != hipSuccess ||
+            hipStreamWaitEvent(s_comm, gev_fork, 0) != hipSuccess)
+            r = fail(CMDG_ERR_HIP, "step graph: fork of the halo stream failed");
+    }
+    if (!r) r = group_lsrk_step(one, Qs, dQs, 0.0, dt, nstages, rka, rkb, rkc, true, d_gtime + 2);
+    const hipError_t ee = hipStreamEndCapture(s_comp, &graph);
+    capturing = false;
+    if (r || ee != hipSuccess || !graph) {
+        if (graph) hipGraphDestroy(graph);
+        abort_exchanges();
+        (void)hipGetLastError();
+        graph_failed = true;
+        if (!r) r = fail(CMDG_ERR_HIP, std::string("step graph: hipStreamEndCapture: ") + hipGetErrorString(ee));
+        return r;
+    }
+    const hipError_t ie = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (ie != hipSuccess) {
+        graph_exec = nullptr;
+        graph_failed = true;
+        return fail(CMDG_ERR_HIP, std::string("step graph: hipGraphInstantiate: ") + hipGetErrorString(ie));
+    }
+    return CMDG_OK;
+}
+
+int EngineBase::run_steps(double *Q, double *dQ, double t, double dt, int64_t nsteps, int nstages,
+                          const double *rka, const double *rkb, const double *rkc)
+{
+    // (the step times accumulate as the reference's updatetime! does: t += dt, ODESolvers.jl:96-98)
+    int64_t i = 0;
+    if (nsteps >= 2 && nstages <= 16 && graph_eligible()) {
+        if (int r = lsrk_step(Q, dQ, t, dt, nstages, rka, rkb, rkc, false)) return r;  // eager: packs Q
+        t += dt;
+        i = 1;
+        GraphKey key;
+        key.Q = Q, key.dQ = dQ, key.dt = dt, key.nstages = nstages;
+        key.comm = communicate() && !(stacked && direction == DIR_VERTICAL);
+        key.pipe = pipelined(key.comm);
+        for (int s = 0; s < nstages; ++s) key.coef[s] = rka[s], key.coef[16 + s] = rkb[s], key.coef[32 + s] = rkc[s];
+        if (!graph_exec || !(key == graph_key)) {
+            if (capture_step(Q, dQ, dt, nstages, rka, rkb, rkc) == CMDG_OK) graph_key = key;
+            // (a failed capture leaves graph_failed set and err says why: the run goes on eagerly)
+        }
+        if (graph_exec && !graph_failed) {
+            StepTimesInit v{};
+            v.t_next = t, v.dt = dt, v.nstages = nstages;
+            for (int s = 0; s < nstages; ++s) v.rkc[s] = rkc[s];
+            hipLaunchKernelGGL(k_step_times_init, dim3(1), dim3(1), 0, s_comp, d_gtime, v);
+            for (; i < nsteps; ++i, t += dt) {
+                HIPCHK(hipGraphLaunch(graph_exec, s_comp));
+                graph_steps += 1;
+            }
+            return CMDG_OK;
+        }
+        // the capture left the exchange state of a continued step behind: start over from Q
+        invalidate_sends();
+        for (; i < nsteps; ++i, t += dt)
+            if (int r = lsrk_step(Q, dQ, t, dt, nstages, rka, rkb, rkc, false)) return r;
+        return CMDG_OK;
+    }
+    for (; i < nsteps; ++i, t += dt)
+        if (int r = lsrk_step(Q, dQ, t, dt, nstages, rka, rkb, rkc, i > 0)) return r;
     return CMDG_OK;
 }
 
@@ -1441,12 +1597,7 @@ int cmdg_lsrk_run(cmdg_handle h, double *Q, double *dQ, double t, double dt, int
 {
     if (!h || !Q || !dQ || !rka || !rkb || !rkc) return CMDG_ERR_INVALID;
     DevGuard guard_(h->eng);
-    // (the step times accumulate as the reference's updatetime! does: t += dt, ODESolvers.jl:96-98)
-    for (int64_t i = 0; i < nsteps; ++i, t += dt) {
-        int r = h->eng->lsrk_step(Q, dQ, t, dt, nstages, rka, rkb, rkc, i > 0);
-        if (r) return set_err(h, r);
-    }
-    return CMDG_OK;
+    return set_err(h, h->eng->run_steps(Q, dQ, t, dt, nsteps, nstages, rka, rkb, rkc));
 }
 
 int cmdg_synchronize(cmdg_handle h)
@@ -1468,6 +1619,11 @@ int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value)
         if (int r = e->synchronize()) return set_err(h, r);
         e->reference_halo = value != 0;
         e->invalidate_sends();
+        return CMDG_OK;
+    case CMDG_OPT_STEP_GRAPH:
+        if (int r = e->synchronize()) return set_err(h, r);
+        e->step_graph = value != 0;
+        e->graph_failed = false;
         return CMDG_OK;
     case CMDG_OPT_HALO_PIPELINE:
         if (int r = e->synchronize()) return set_err(h, r);
@@ -1491,6 +1647,9 @@ int cmdg_query(cmdg_handle h, int32_t what, int64_t *out)
     case CMDG_Q_DIRECT_SEND: *out = e->communicate() && e->direct_send(); return CMDG_OK;
     case CMDG_Q_DIRECT_RECV: *out = e->communicate() && e->direct_recv(); return CMDG_OK;
     case CMDG_Q_TENDENCY_ELEMS_PER_GROUP: *out = e->tendency_epb(); return CMDG_OK;
+    case CMDG_Q_GRAPH_STEPS: *out = e->graph_steps; return CMDG_OK;
+    case CMDG_Q_HOST_POST_NS: *out = e->host_post_ns; return CMDG_OK;
+    case CMDG_Q_HOST_POST_COUNT: *out = e->host_post_n; return CMDG_OK;
     case CMDG_Q_HALO_PIPELINE:
         *out = e->pipelined(e->communicate() && !(e->stacked && e->direction == DIR_VERTICAL)) && !e->has_hooks;
         return CMDG_OK;

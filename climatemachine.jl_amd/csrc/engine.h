@@ -36,6 +36,7 @@ struct RhsCtx {
     double *Qin = nullptr;   // state read by this evaluation (ghosts refreshed in place)
     double *Qout = nullptr;  // LSRK: updated state
     double t = 0, alpha = 1, beta = 0;
+    const double *tptr = nullptr;  // time in device memory instead (captured steps)
     bool lsrk = false;         // fused update inside k_tendency
     bool update_after = false; // separate update!() after the (filtered) tendency
     double rkb_dt = 0, rka_next = 0;
@@ -199,6 +200,7 @@ struct EngineBase {
     // max(I_p, X_p) + E_p.
     hipEvent_t ev_int[2] = {nullptr, nullptr}, ev_ext[2] = {nullptr, nullptr};
     int64_t pass_seq = 0;  // passes started on this handle
+    int64_t host_post_ns = 0, host_post_n = 0;  // host time inside halo_post (RCCL group calls)
     hipEvent_t prof_ext_done = nullptr;  // profiling: end of the last exterior launch
     bool no_pipeline = false;  // CMDG_OPT_HALO_PIPELINE = 0
     bool pipelined(bool comm) const
@@ -215,6 +217,49 @@ struct EngineBase {
         slot[s].fresh_for = array;
         slot[s].fresh_nvar = nvar;
     }
+
+    // ---- a whole LSRK step as a HIP graph (CMDG_OPT_STEP_GRAPH) ---------------------------
+    // cmdg_lsrk_run can record one step into a HIP graph and replay it: the evaluation times come
+    // from device memory, advanced by a one-thread kernel at the head of the graph exactly as
+    // updatetime! accumulates them; the first step of every run is issued eagerly, the capture uses
+    // events of its own.  Built for the partitioned case -- at 5 400 elements per rank a step is
+    // bound by the HOST: posting an RCCL group costs 55 us of host time, 20 of them per step, next
+    // to 40 kernel launches and 100 event operations (1.43 ms of enqueueing for a 1.56 ms step) --
+    // but RCCL operations inside a capture crash hipStreamEndCapture on this stack, so handles that
+    // exchange stay eager (graph_eligible) and the option serves single-rank handles only, where
+    // the device is the bound anyway.  Anything else a capture cannot hold (profiling, filters,
+    // hooks, an unfused nodal refresh) keeps a run eager too.
+    bool step_graph = false;        // the option
+    bool capturing = false;         // rhs_segment is being recorded
+    int cap_interior = 0, cap_exterior = 0;  // launches begun in this capture
+    // (every record of a capture gets an event of its own: 4 passes x 16 stages at most)
+    static constexpr int NGEV = 64;
+    hipEvent_t gev_int[NGEV] = {nullptr}, gev_ext[NGEV] = {nullptr}, gev_fork = nullptr;
+    int cap_pass = 0;  // passes begun in this capture
+    hipGraphExec_t graph_exec = nullptr;
+    struct GraphKey {
+        const double *Q = nullptr, *dQ = nullptr;
+        double dt = 0;
+        int nstages = 0;
+        double coef[48] = {0};
+        bool pipe = false, comm = false;
+        bool operator==(const GraphKey &o) const
+        {
+            if (Q != o.Q || dQ != o.dQ || dt != o.dt || nstages != o.nstages || pipe != o.pipe || comm != o.comm)
+                return false;
+            for (int i = 0; i < 48; ++i)
+                if (coef[i] != o.coef[i]) return false;
+            return true;
+        }
+    } graph_key;
+    double *d_gtime = nullptr;      // [t_next, dt, times[16], rkc[16]]
+    int64_t graph_steps = 0;        // steps replayed from the graph (cmdg_query)
+    bool graph_failed = false;      // a capture failed: this handle stays eager
+    bool graph_eligible() const;
+    int capture_step(double *Q, double *dQ, double dt, int nstages, const double *rka,
+                     const double *rkb, const double *rkc);
+    int run_steps(double *Q, double *dQ, double t, double dt, int64_t nsteps, int nstages,
+                  const double *rka, const double *rkb, const double *rkc);
 
     // orchestration
     static constexpr int NSEG = 6;
@@ -299,7 +344,7 @@ namespace cmdg {
 int group_rhs(std::vector<EngineBase *> &g, std::vector<RhsCtx> &c, bool keep_fresh = false);
 int group_lsrk_step(std::vector<EngineBase *> &g, double **Q, double **dQ, double t, double dt,
                     int nstages, const double *rka, const double *rkb, const double *rkc,
-                    bool continued = false);
+                    bool continued = false, const double *stage_times_dev = nullptr);
 
 // ---------------------------------------------------------------------------------
 template <class P, int NQ_, int NQV_ = NQ_>
@@ -322,6 +367,7 @@ struct EngineT : EngineBase {
         a.tendency = c.tendency;
         a.Qout = c.Qout;
         a.t = c.t;
+        a.tptr = c.tptr;
         a.alpha = c.alpha;
         a.beta = c.beta;
         a.rkb_dt = c.rkb_dt;

@@ -75,6 +75,8 @@ struct PassArgs {
     double *tendency;  // tendency (== dQ when the LSRK update is fused)
     double *Qout;      // LSRK: updated state
     double t, alpha, beta;
+    const double *tptr;  // time of the evaluation in device memory (a captured step is replayed
+                         // with the time a one-thread kernel of the graph advances); NULL: t
     double rkb_dt, rka_next;
     int direction;     // direction of this pass (dg.direction or dg.diffusion_direction)
     int model_dir;     // dg.direction handed to the pointwise fluxes
@@ -395,6 +397,7 @@ __global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, MODE>()),
     k_tendency(const PassArgs<P> a)
 {
     using KD = KDims<NQ, NQV>;
+    const double a_t = a.tptr ? *a.tptr : a.t;  // (uniform: one scalar load)
     using SH = TendencyShape<P, NQ, NQV>;
     constexpr int EPB = SH::EPB;
     constexpr bool VOL = MODE != TEND_FACES, FACES = MODE != TEND_VOLUME;
@@ -517,10 +520,10 @@ __global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, MODE>()),
                     sM[(OCA + s) * NSURF + sidx] = lc[s];
             }
         } else {
-            P::flux_first_order(a.prm, F, lQ, laux, a.t, a.model_dir);
+            P::flux_first_order(a.prm, F, lQ, laux, a_t, a.model_dir);
         }
         F2.negzero();
-        P::flux_second_order(a.prm, F2, lQ, lgf, lhyp, laux, a.t);
+        P::flux_second_order(a.prm, F2, lQ, lgf, lhyp, laux, a_t);
 #pragma unroll
         for (int q = 0; q < 3 * NS; ++q) F[q] += F2[q];
         if (hz) {
@@ -546,7 +549,7 @@ __global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, MODE>()),
         if constexpr (P::HAS_SOURCE) {
             Vec<P::NDER> lder;
             load_state<P::NDER, Np>(lder, a.derived, tid, e);
-            P::source(a.prm, S, lQ, lgf, laux, lder, a.t, a.model_dir);
+            P::source(a.prm, S, lQ, lgf, laux, lder, a_t, a.model_dir);
         }
 #endif
     }
@@ -668,14 +671,14 @@ __global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, MODE>()),
             for (int s = 0; s < NAUX; ++s) auxPd[s] = auxPn[s];
             flux.negzero();
             if (fp.bctag == 0) {
-                nf_first_order<P>(a.prm, a.nf_first, flux, fp.n, QM, auxM, QPn, auxPn, a.t,
+                nf_first_order<P>(a.prm, a.nf_first, flux, fp.n, QM, auxM, QPn, auxPn, a_t,
                                   facedir, NCA > 0 ? (const double *)cM : nullptr);
                 // CentralNumericalFluxSecondOrder  NumericalFluxes.jl:670-715
                 Vec<3 * NS> FM, FP;
                 FM.negzero();
-                P::flux_second_order(a.prm, FM, QM, gfM, hypM, auxM, a.t);
+                P::flux_second_order(a.prm, FM, QM, gfM, hypM, auxM, a_t);
                 FP.negzero();
-                P::flux_second_order(a.prm, FP, QPd, gfP, hypP, auxPd, a.t);
+                P::flux_second_order(a.prm, FP, QPd, gfP, hypP, auxPd, a_t);
                 const double nh0 = fp.n[0] / 2, nh1 = fp.n[1] / 2, nh2 = fp.n[2] / 2;
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
@@ -700,15 +703,15 @@ __global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, MODE>()),
                     if (use_gf) load_state<NGF, Np>(gf1, a.gf, n + NQ * NQ, e);
                 }
                 // numerical_boundary_flux_first_order!  NumericalFluxes.jl:163-205
-                P::boundary_state(a.prm, BS_FIRST, fp.bctag, QPn, auxPn, fp.n, QM, auxM, a.t, Q1,
+                P::boundary_state(a.prm, BS_FIRST, fp.bctag, QPn, auxPn, fp.n, QM, auxM, a_t, Q1,
                                   aux1);
-                nf_first_order<P>(a.prm, a.nf_first, flux, fp.n, QM, auxM, QPn, auxPn, a.t,
+                nf_first_order<P>(a.prm, a.nf_first, flux, fp.n, QM, auxM, QPn, auxPn, a_t,
                                   facedir, NCA > 0 ? (const double *)cM : nullptr);
                 // normal_boundary_flux_second_order!  NumericalFluxes.jl:872-918
                 Vec<3 * NS> FP;
                 FP.negzero();
                 P::boundary_flux_second_order(a.prm, fp.bctag, FP, QPd, gfP, hypP, auxPd, fp.n, QM,
-                                              gfM, hypM, auxM, a.t, Q1, gf1, aux1);
+                                              gfM, hypM, auxM, a_t, Q1, gf1, aux1);
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
                     flux[s] +=
@@ -823,6 +826,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LA
                                    (NQ == 5 && NQV == 5 ? grad_min_waves<P>::value : 1)) k_gradients(const PassArgs<P> a)
 {
     using KD = KDims<NQ, NQV>;
+    const double a_t = a.tptr ? *a.tptr : a.t;  // (uniform: one scalar load)
     constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGRAD = P::NGRAD,
                   NGF = USE_GF ? P::NGF : 0, NGL = P::NGL, NHG = 3 * NGL, NACC = NGF + NHG;
     constexpr unsigned GMASK = gradient_argument_mask<P, USE_GF>();
@@ -849,7 +853,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LA
         if constexpr (P::HAS_UPDATE_AUX && P::FUSE_UPDATE_AUX) {
             // kernel_nodal_update_auxiliary_state! of the real elements, fused: the refreshed
             // entries are read by no kernel of this evaluation (see P::FUSE_UPDATE_AUX)
-            P::update_aux(a.prm, lQ, laux, a.t);
+            P::update_aux(a.prm, lQ, laux, a_t);
 #pragma unroll
             for (int s = 0; s < P::NUPD; ++s)
                 a.aux_rw[tid + (int64_t)Np * (P::upd_aux(s) + (int64_t)NAUX * e)] =
@@ -857,7 +861,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LA
         }
         Vec<NGRAD> G;
         G.negzero();
-        P::gradient_argument(a.prm, G, lQ, laux, a.t);
+        P::gradient_argument(a.prm, G, lQ, laux, a_t);
 #pragma unroll
         for (int s = 0; s < NGRAD; ++s)
             if (GMASK >> s & 1) sG[s * Np + tid] = G[s];
@@ -950,8 +954,8 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LA
             Vec<NGRAD> Gn;  // this node's gradient argument (every entry is staged when NGF > 0)
 #pragma unroll
             for (int s = 0; s < NGRAD; ++s) Gn[s] = (GMASK >> s & 1) ? sG[s * Np + tid] : 0.0;
-            if (hz) law_gradient_flux<P>(a.prm, o1, gh, lQ, laux, a.t, Gn);
-            if (vt) law_gradient_flux<P>(a.prm, o2, gv, lQ, laux, a.t, Gn);
+            if (hz) law_gradient_flux<P>(a.prm, o1, gh, lQ, laux, a_t, Gn);
+            if (vt) law_gradient_flux<P>(a.prm, o2, gv, lQ, laux, a_t, Gn);
 #pragma unroll
             for (int s = 0; s < NGF; ++s)
                 sA[s * Np + tid] = hz ? (vt ? o1[s] + o2[s] : o1[s]) : o2[s];
@@ -985,7 +989,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LA
                 load_plus<NS, Np, NS>(QP, a.Q, a.h.recvQ, ghost_slot<Np>(a.h, fp.eP, fp.vidP), fp.vidP,
                                       fp.eP);
                 load_state<NAUX, Np>(auxP, a.aux, fp.vidP, fp.eP);
-                P::gradient_argument(a.prm, GP, QP, auxP, a.t);
+                P::gradient_argument(a.prm, GP, QP, auxP, a_t);
 #pragma unroll
                 for (int s = 0; s < NGRAD; ++s)
 #pragma unroll
@@ -1005,15 +1009,15 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LA
                     load_state<NS, Np>(Q1, a.Q, n + NQ * NQ, e);
                     load_state<NAUX, Np>(aux1, a.aux, n + NQ * NQ, e);
                 }
-                P::boundary_state(a.prm, BS_GRADIENT, fp.bctag, QP, auxP, fp.n, QM, auxM, a.t, Q1,
+                P::boundary_state(a.prm, BS_GRADIENT, fp.bctag, QP, auxP, fp.n, QM, auxM, a_t, Q1,
                                   aux1);
-                P::gradient_argument(a.prm, GP, QP, auxP, a.t);
+                P::gradient_argument(a.prm, GP, QP, auxP, a_t);
 #pragma unroll
                 for (int s = 0; s < NGRAD; ++s)
 #pragma unroll
                     for (int d = 0; d < 3; ++d) tg[d + 3 * s] = fp.n[d] * GP[s];
             }
-            if constexpr (NGF > 0) law_gradient_flux<P>(a.prm, lgf, tg, QM, auxM, a.t, GM);
+            if constexpr (NGF > 0) law_gradient_flux<P>(a.prm, lgf, tg, QM, auxM, a_t, GM);
 #pragma unroll
             for (int s = 0; s < NGRAD; ++s)
 #pragma unroll
@@ -1028,7 +1032,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LA
             if constexpr (NGF > 0) {
                 Vec<NGF> visc;
                 for (int s = 0; s < NGF; ++s) visc[s] = 0;
-                law_gradient_flux<P>(a.prm, visc, nGM, QM, auxM, a.t, GM);
+                law_gradient_flux<P>(a.prm, visc, nGM, QM, auxM, a_t, GM);
 #pragma unroll
                 for (int s = 0; s < NGF; ++s) corr[s] = fp.vMI * fp.sM * (lgf[s] - visc[s]);
             }
@@ -1066,6 +1070,7 @@ template <class P, int NQ, int NQV = NQ>
 __global__ void __launch_bounds__((KDims<NQ, NQV>::NT)) k_divgrad(const PassArgs<P> a)
 {
     using KD = KDims<NQ, NQV>;
+    const double a_t = a.tptr ? *a.tptr : a.t;  // (uniform: one scalar load)
     constexpr int Np = KD::Np, NAUX = P::NAUX, NGL = P::NGL, NHG = 3 * NGL,
                   NHYP = P::NHYP, NG = NGL > 0 ? NGL : 1;
     __shared__ double sD[NQ * NQ + (NQV == NQ ? 0 : NQV * NQV)];
@@ -1153,7 +1158,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT)) k_divgrad(const PassArgs
                 Vec<NAUX> auxM, auxP;
                 load_state<NAUX, Np>(auxM, a.aux, fp.vidM, e);
                 load_state<NAUX, Np>(auxP, a.aux, fp.vidP, fp.eP);
-                P::boundary_state_divergence(a.prm, fp.bctag, gP, auxP, fp.n, gM, auxM, a.t);
+                P::boundary_state_divergence(a.prm, fp.bctag, gP, auxP, fp.n, gM, auxM, a_t);
             }
             // CentralNumericalFluxDivergence  NumericalFluxes.jl:720-730
             const double nh0 = fp.n[0] / 2, nh1 = fp.n[1] / 2, nh2 = fp.n[2] / 2;
@@ -1193,6 +1198,7 @@ template <class P, int NQ, int NQV = NQ>
 __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_LAP_MINW) k_gradlap(const PassArgs<P> a)
 {
     using KD = KDims<NQ, NQV>;
+    const double a_t = a.tptr ? *a.tptr : a.t;  // (uniform: one scalar load)
     constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGL = P::NGL,
                   NHG = 3 * NGL, NHYP = P::NHYP, NG = NGL > 0 ? NGL : 1,
                   NH = NHYP > 0 ? NHYP : 1;
@@ -1258,8 +1264,8 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_LAP_MINW) k_gradlap
         Vec<NHYP> h1, h2;
         h1.negzero();
         h2.negzero();
-        if (hz) P::post_gradient_laplacian(a.prm, h1, lh, lQ, laux, a.t);
-        if (vt) P::post_gradient_laplacian(a.prm, h2, lv, lQ, laux, a.t);
+        if (hz) P::post_gradient_laplacian(a.prm, h1, lh, lQ, laux, a_t);
+        if (vt) P::post_gradient_laplacian(a.prm, h2, lv, lQ, laux, a_t);
 #pragma unroll
         for (int s = 0; s < NHYP; ++s) sA[s * Np + tid] = hz ? (vt ? h1[s] + h2[s] : h1[s]) : h2[s];
     }
@@ -1286,7 +1292,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_LAP_MINW) k_gradlap
             load_plus<NHYP, Np, NGL, NGL>(lapP, a.hypdiv, a.h.recvHD, gslot, fp.vidP, fp.eP);
             if (fp.bctag != 0)  // numerical_boundary_flux_higher_order!  :792-832
                 P::boundary_state_higher_order(a.prm, fp.bctag, QP, auxP, lapP, fp.n, QM, auxM,
-                                               lapM, a.t);
+                                               lapM, a_t);
             // CentralNumericalFluxHigherOrder  NumericalFluxes.jl:768-790
             Vec<NHG> G;
 #pragma unroll
@@ -1295,7 +1301,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_LAP_MINW) k_gradlap
                 for (int d = 0; d < 3; ++d) G[d + 3 * s] = fp.n[d] * (lapP[s] - lapM[s]) / 2;
             Vec<NHYP> lh;
             for (int s = 0; s < NHYP; ++s) lh[s] = 0;
-            P::post_gradient_laplacian(a.prm, lh, G, QM, auxM, a.t);
+            P::post_gradient_laplacian(a.prm, lh, G, QM, auxM, a_t);
 #pragma unroll
             for (int s = 0; s < NHYP; ++s) corr[s] = fp.vMI * fp.sM * lh[s];
             vidM = fp.vidM;

@@ -193,10 +193,16 @@ int cmdg_synchronize(cmdg_handle h);
  *   and the exchange it feeds (a chain without event hops), and the interior list on the compute
  *   stream one pass behind or ahead (the passes of a step form two loosely coupled pipelines).
  *   0: the reference's order on one compute stream (interior launch, wait, exterior launch).
- *   Results do not depend on it. */
+ *   Results do not depend on it.
+ * CMDG_OPT_STEP_GRAPH (default 0; environment CMDG_STEP_GRAPH=1): cmdg_lsrk_run records one step
+ *   into a HIP graph and replays it for every step but the first of a run; the evaluation times
+ *   live in device memory and advance as updatetime! does.  Results are bit-identical.
+ *   Single-rank handles only: handles that exchange stay eager (RCCL operations inside a stream
+ *   capture crash hipStreamEndCapture with RCCL 2.26.6 / ROCm 7.0.2), and so do runs a capture
+ *   cannot hold (profiling, filters, hooks, a nodal update_auxiliary_state! kernel of its own). */
 enum {
     CMDG_OPT_KEEP_GRADFLUX = 1, CMDG_OPT_STACK_HEIGHT = 2, CMDG_OPT_REFERENCE_HALO = 3,
-    CMDG_OPT_HALO_PIPELINE = 4
+    CMDG_OPT_HALO_PIPELINE = 4, CMDG_OPT_STEP_GRAPH = 5
 };
 int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value);
 
@@ -216,6 +222,9 @@ enum {
     CMDG_Q_NUPDATED_AUX = 4, CMDG_Q_FUSED_UPDATE_AUX = 5, CMDG_Q_DIRECT_SEND = 6,
     CMDG_Q_DIRECT_RECV = 7, CMDG_Q_TENDENCY_ELEMS_PER_GROUP = 8,
     CMDG_Q_HALO_PIPELINE = 9, /* are the two pipelines of CMDG_OPT_HALO_PIPELINE in use */
+    CMDG_Q_HOST_POST_NS = 10,   /* host nanoseconds spent posting exchanges (RCCL group calls) ... */
+    CMDG_Q_HOST_POST_COUNT = 11, /* ... and how many were posted, since the handle was created */
+    CMDG_Q_GRAPH_STEPS = 12,     /* steps cmdg_lsrk_run replayed from a captured graph */
     CMDG_Q_STATE_READ = 16, CMDG_Q_AUX_READ = 20
 };
 int cmdg_query(cmdg_handle h, int32_t what, int64_t *out);

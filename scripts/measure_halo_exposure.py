@@ -70,15 +70,18 @@ def main():
     solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
     solver.dostep(Q, nsteps=20)
     dg.synchronize()
-    runs = []
+    runs, enq = [], []
+    h0 = (dg.query("HOST_POST_NS"), dg.query("HOST_POST_COUNT"))
     for _ in range(args.repeat):
         Q.copy_(dg.init_ode_state(0.0))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         solver.dostep(Q, nsteps=args.steps)
+        enq.append(time.perf_counter() - t0)      # the host is done enqueueing (the run is asynchronous)
         dg.synchronize()
         runs.append(time.perf_counter() - t0)
     el = min(runs)
+    h1 = (dg.query("HOST_POST_NS"), dg.query("HOST_POST_COUNT"))
     Q.copy_(dg.init_ode_state(0.0))
     torch.cuda.synchronize()
     dg.profile_reset()
@@ -93,7 +96,9 @@ def main():
            "bytes_per_exchange_per_state_column": int(8 * len(grid.vmapsend)),
            "exchange": modes,
            "ms_per_step": 1e3 * el / args.steps, "steps": args.steps,
-           "ms_per_step_runs": [1e3 * r / args.steps for r in runs], "kernels": {}}
+           "ms_per_step_runs": [1e3 * r / args.steps for r in runs],
+           "host_enqueue_ms_per_step": 1e3 * min(enq) / args.steps,
+           "host_rccl_post_us_per_exchange": 1e-3 * (h1[0] - h0[0]) / max(h1[1] - h0[1], 1), "kernels": {}}
     for k in ("GRADIENTS", "GRADIENTS_EXT", "DIVGRAD", "DIVGRAD_EXT", "GRADLAP", "GRADLAP_EXT", "TENDENCY",
               "TENDENCY_EXT", "PACK", "TRANSPORT", "UNPACK", "HALO_EXPOSED"):
         ms, n = dg.profile_get(k)

@@ -220,3 +220,41 @@ def test_switching_between_one_stream_and_two_pipelines(cm, torch):
     for a, b in zip(*out):
         assert np.isfinite(a).all()
         assert np.array_equal(a, b)
+
+
+def test_step_graph_equals_eager_steps(cm, torch):
+    """CMDG_OPT_STEP_GRAPH: cmdg_lsrk_run replays one captured step (stage times from device
+    memory, advanced as updatetime! does) for every step but the first of a run.  Same bits as
+    eager steps; two runs reuse the graph; the time really advances (the advection-diffusion
+    law's boundary data depend on it).  A handle that exchanges stays eager: RCCL operations
+    inside a stream capture crash hipStreamEndCapture on this stack (csrc/cmdg.hip,
+    graph_eligible)."""
+    from helpers import pseudo1d_setup
+    from test_gpu_halo import _self_neighbour_grid
+    out, counts = [], []
+    for graph in (0, 1):
+        law, grid, dt = pseudo1d_setup(direction=0)
+        dg = cm.dgmodel.DGModel(law, grid, direction=0)
+        dg.set_option(cm._lib.OPT_STEP_GRAPH, graph)
+        Q = dg.init_ode_state(0.0)
+        solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+        solver.dostep(Q, nsteps=4)
+        solver.dostep(Q, nsteps=3)
+        dg.synchronize()
+        counts.append(dg.query("GRAPH_STEPS"))
+        out.append(Q[:grid.nreal].cpu().numpy().copy())
+        dg.close()
+    assert counts == [0, 3 + 2], counts
+    assert np.isfinite(out[0]).all() and np.abs(out[0]).max() > 0
+    assert np.array_equal(out[0], out[1])
+    # with neighbours the option changes nothing
+    grid = _self_neighbour_grid(cm, 0, 2)
+    grid.nabrtorank = [0] * len(grid.nabrtorank)
+    dg = cm.dgmodel.DGModel(pseudo1d_setup()[0], grid, direction=0)
+    dg.comm_init_rccl(cm.dgmodel.rccl_unique_id(), 0, 1)
+    dg.set_option(cm._lib.OPT_STEP_GRAPH, 1)
+    Q = dg.init_ode_state(0.0)
+    cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=1e-4).dostep(Q, nsteps=3)
+    dg.synchronize()
+    assert dg.query("GRAPH_STEPS") == 0 and torch.isfinite(Q[:grid.nreal]).all()
+    dg.close()
