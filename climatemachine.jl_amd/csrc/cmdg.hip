@@ -984,7 +984,7 @@ int EngineBase::run_steps(double *Q, double *dQ, double t, double dt, int64_t ns
         for (int s = 0; s < nstages; ++s) key.coef[s] = rka[s], key.coef[16 + s] = rkb[s], key.coef[32 + s] = rkc[s];
         if (!graph_exec || !(key == graph_key)) {
             if (capture_step(Q, dQ, dt, nstages, rka, rkb, rkc) == CMDG_OK) graph_key = key;
-            // (a failed capture leaves graph_failed set and err says why: the run goes on eagerly)
+            else graph_failed = true;  // err says why; this run and the later ones go on eagerly
         }
         if (graph_exec && !graph_failed) {
             StepTimesInit v{};
