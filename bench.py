@@ -30,6 +30,27 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+_RESULT_OUT = None
+
+
+def claim_stdout():
+    """stdout carries the ONE JSON line of the contract, but RCCL (and any other native library)
+    writes banners and warnings to file descriptor 1 as well.  A rank therefore keeps a private
+    handle on the real stdout for its result and points descriptor 1 at stderr for everything
+    else, native code included."""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    out = _RESULT_OUT or sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def build_workload(cm, name, rank, size, ne, args, nhorz=None, nvert=None):
     """Returns (law, grid, direction, dt, description)."""
     M, BL = cm.mesh, cm.balancelaws
@@ -645,7 +666,7 @@ def main(argv=None):
                "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
                "gpus": args.gpus, "torch_imported": "torch" in sys.modules}
         if rank == 0:
-            print(json.dumps({"dry_launch": rec}), flush=True)
+            emit({"dry_launch": rec})
         else:
             log("[dry-launch] %s" % json.dumps(rec))
         if os.environ.get("BENCH_DRY_FAIL_RANK") == str(rank):
@@ -653,6 +674,7 @@ def main(argv=None):
         return
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    claim_stdout()
     if args.workload == "ocean-split-explicit":
         return main_ocean(args, rank, world, local)
 
@@ -737,7 +759,7 @@ def main(argv=None):
                                 "value": r2["value"], "ms_per_step": r2["ms_per_step"]}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(cm, law, grid, direction, dt, args.cpu_budget, args)
-        print(json.dumps(out), flush=True)
+        emit(out)
         if not out["state_finite"]:
             raise SystemExit("bench.py: the state is not finite after the timed steps")
     if distributed:
@@ -900,7 +922,7 @@ def main_ocean(args, rank, world, local):
         out["cpu_baseline"] = {"value": g3.nreal * g3.Np * law3.ns * 5 / c, "unit": "DOF-updates/s",
                                "cores": OR.get_max_threads(), "kind": "port",
                                "sample": "1 slow step of the same workload in %.1f s, OpenMP over elements" % c}
-    print(json.dumps(out), flush=True)
+    emit(out)
     del keep
     dg3.close(), dg2.close()
     if distributed:

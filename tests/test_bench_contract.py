@@ -112,3 +112,15 @@ def test_launcher_fails_when_a_rank_fails():
     r = _bench("--gpus", "2", "--dry-launch", env={"RANK": "1", "WORLD_SIZE": "2", "LOCAL_RANK": "1",
                                                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "1"})
     assert r.returncode == 0 and r.stdout.strip() == "" and "[dry-launch]" in r.stderr
+
+
+def test_result_line_survives_native_output_on_stdout():
+    """RCCL prints warnings to file descriptor 1; a rank keeps the real stdout for its one JSON
+    line and sends everything else written to descriptor 1 to stderr (bench.claim_stdout)."""
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.claim_stdout(); "
+            "os.write(1, b'NCCL WARN something native\\n'); print('python chatter'); "
+            "bench.emit({'metric': 'x', 'value': 1})" % os.path.dirname(bench.__file__))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip().splitlines() == ['{"metric": "x", "value": 1}']
+    assert "NCCL WARN something native" in r.stderr and "python chatter" in r.stderr
