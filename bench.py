@@ -18,6 +18,12 @@ import os
 import sys
 import time
 
+# The CPU baseline's OpenMP threads stay where their first touch put their pages.  libgomp reads
+# these when it is loaded (with torch or with liboracle.so, whichever comes first), so they are set
+# before either; nothing on the GPU path depends on them.
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -235,8 +241,10 @@ def _oracle_steps(O, law, grid, direction, dt, budget_s, max_steps, warm_rhs=Tru
                          diffusion_direction=direction[1])
     Q = law.init_state_prognostic(grid, dg.state_auxiliary, 0.0)
     dQ = np.zeros_like(Q)
+    dg.numa_distribute()                         # first touch by the thread that owns the elements
+    Q, dQ = O.first_touch(Q), O.first_touch(dQ)
     if warm_rhs:                                 # page faults + thread pool: one RHS evaluation
-        dg(np.zeros_like(Q), Q.copy(), 0.0, 1.0, 0.0)
+        dg(O.first_touch(np.zeros_like(Q)), O.first_touch(Q), 0.0, 1.0, 0.0)
     n, t0 = 0, time.time()
     while True:
         O.lsrk54_step(dg, Q, dQ, n * dt, dt)
@@ -247,6 +255,49 @@ def _oracle_steps(O, law, grid, direction, dt, budget_s, max_steps, warm_rhs=Tru
     return grid.nreal * grid.Np * law.ns * 5 * n / el, n, el
 
 
+def host_cpu_info():
+    """What this process may use of the host: hardware threads in its affinity mask, the cgroup
+    CPU quota (a container may see 128 threads and be allowed 16 CPUs' worth of time), sockets
+    and physical cores behind the mask."""
+    info = {"affinity_threads": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": None,
+            "sockets": None, "physical_cores": None}
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            info["cgroup_cpu_quota"] = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                info["cgroup_cpu_quota"] = q / per
+        except Exception:
+            pass
+    try:
+        cores, cpu = set(), {}
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if "processor" in cpu and int(cpu["processor"]) in os.sched_getaffinity(0):
+                    cores.add((cpu.get("physical id", "0"), cpu.get("core id", cpu["processor"])))
+                cpu = {}
+                continue
+            k, v = line.split(":", 1)
+            cpu[k.strip()] = v.strip()
+        info["sockets"] = len({c[0] for c in cores}) or None
+        info["physical_cores"] = len(cores) or None
+    except Exception:
+        pass
+    return info
+
+
+def baseline_threads(info, omp_max):
+    """Threads the all-core figure runs on: one per hardware thread this process may keep busy."""
+    n = min(omp_max, info["affinity_threads"])
+    if info["cgroup_cpu_quota"]:
+        n = min(n, max(1, int(info["cgroup_cpu_quota"] + 0.5)))
+    return max(1, n)
+
+
 def cpu_baseline(cm, law, grid, direction, dt, budget_s, args):
     """The oracle (CPU restatement of the reference kernels in the reference's unfused launch
     order: horizontal then vertical volume kernel, per-direction interface launches, separate
@@ -255,7 +306,9 @@ def cpu_baseline(cm, law, grid, direction, dt, budget_s, args):
     minutes on one core)."""
     from oracle import oracle as O
     O.build()
-    cores = O.get_max_threads()
+    host = host_cpu_info()
+    cores = baseline_threads(host, O.get_max_threads())
+    O.set_num_threads(cores)
     what = "the same workload"
     if args.workload == "bomex" and args.bomex_ne > 16:
         # bounded sample: one oracle step of the 65 536-element box takes minutes on the host
@@ -267,7 +320,12 @@ def cpu_baseline(cm, law, grid, direction, dt, budget_s, args):
     v, n, el = _oracle_steps(O, law, grid, direction, dt, budget_s, 50)
     out = {"value": v, "unit": "DOF-updates/s", "cores": cores, "kind": "port",
            "sample": "%d LSRK54 step(s) of %s (%d elements) in %.1f s, "
-                     "OpenMP over elements, after one untimed RHS evaluation" % (n, what, grid.nreal, el)}
+                     "OpenMP over elements, after one untimed RHS evaluation" % (n, what, grid.nreal, el),
+           # how the threads were placed, and the memory-bandwidth ceiling they reach together
+           "threads": cores, "host": host,
+           "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
+           "first_touch": "every per-element array re-homed by an OpenMP static loop over elements",
+           "stream_triad_GBs": round(O.stream_triad_gbs(), 1)}
     if args.workload == "heldsuarez":
         law1, grid1, dir1, dt1, _ = build_workload(cm, "heldsuarez", 0, 1, 0, args, nhorz=4)
         O.set_num_threads(1)
@@ -909,6 +967,8 @@ def main_ocean(args, rank, world, local):
     if not args.no_cpu and world == 1:
         from oracle import oracle as OR
         OR.build()
+        host = host_cpu_info()
+        OR.set_num_threads(baseline_threads(host, OR.get_max_threads()))
         F = cm.mesh.filters
         o3 = OR.OracleDGModel(law3, g3)
         OR.hydrostatic_boussinesq_hooks(o3, F.CutoffFilter(g3, 3), F.ExponentialFilter(g3, 1, 8))
@@ -920,7 +980,7 @@ def main_ocean(args, rank, world, local):
         so.dostep(q3, q2, 0.0)
         c = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": g3.nreal * g3.Np * law3.ns * 5 / c, "unit": "DOF-updates/s",
-                               "cores": OR.get_max_threads(), "kind": "port",
+                               "cores": OR.get_max_threads(), "kind": "port", "host": host,
                                "sample": "1 slow step of the same workload in %.1f s, OpenMP over elements" % c}
     emit(out)
     del keep

@@ -102,6 +102,15 @@ void roctx_pop()
     if (g_roctx_state == 1) g_roctx_pop();
 }
 
+int dbg_sync()
+{
+    static const int v = [] {
+        const char *p = getenv("CMDG_DBG_SYNC");
+        return p ? atoi(p) : 0;
+    }();
+    return v;
+}
+
 // ---------------------------------------------------------------------------------
 EngineBase::~EngineBase()
 {
@@ -365,7 +374,10 @@ int EngineBase::init_halo_tables()
 int EngineBase::before_direct_send(int s, hipStream_t st)
 {
     if (transport == TRANSPORT_LOCAL && communicate() && direct_send())
-        for (int r : nabrtorank) HIPCHK(hipStreamWaitEvent(st, group[r]->slot[s].ev_pulled, 0));
+        for (int r : nabrtorank) {
+            if (dbg_sync() & 32) HIPCHK(hipStreamSynchronize(group[r]->s_comm));
+            HIPCHK(hipStreamWaitEvent(st, group[r]->slot[s].ev_pulled, 0));
+        }
     return CMDG_OK;
 }
 
@@ -448,12 +460,16 @@ int EngineBase::halo_pack(int s, double *array, int nvar, int ncol, bool on_halo
     if (capturing && !(fresh && on_halo_stream))
         return fail(CMDG_ERR_UNSUPPORTED, "step graph: an exchange of this step would have to be packed");
     if (!(fresh && on_halo_stream)) {
+        if (dbg_sync() & 2) HIPCHK(hipStreamSynchronize(s_comp));
         HIPCHK(hipEventRecord(ev_comp, s_comp));
         HIPCHK(hipStreamWaitEvent(s_comm, ev_comp, 0));
     }
     if (transport == TRANSPORT_LOCAL) {
         // neighbours must have pulled the previous payload of this slot
-        for (int r : nabrtorank) HIPCHK(hipStreamWaitEvent(s_comm, group[r]->slot[s].ev_pulled, 0));
+        for (int r : nabrtorank) {
+            if (dbg_sync() & 4) HIPCHK(hipStreamSynchronize(group[r]->s_comm));
+            HIPCHK(hipStreamWaitEvent(s_comm, group[r]->slot[s].ev_pulled, 0));
+        }
     }
     if (nvmapsend > 0 && !fresh) {
         const int64_t n = nvmapsend * nvar;
@@ -573,6 +589,7 @@ int EngineBase::halo_end(int s, double *array, int nvar, bool unpack, bool on_ha
             const int64_t r0 = nabrrecv[2 * n] - 1, rn = nabrrecv[2 * n + 1] - r0;
             const int64_t s0 = peer->nabrsend[2 * m] - 1, sn = peer->nabrsend[2 * m + 1] - s0;
             if (rn != sn) return fail(CMDG_ERR_COMM, "local transport: send/recv sizes differ");
+            if (dbg_sync() & 8) HIPCHK(hipStreamSynchronize(peer->s_comm));
             HIPCHK(hipStreamWaitEvent(s_comm, peer->slot[s].ev_packed, 0));
             if (n == 0) prof_begin(CMDG_K_TRANSPORT, s_comm);
             HIPCHK(hipMemcpyAsync(h.recvbuf + r0 * nvar, peer->slot[s].sendbuf + s0 * nvar,
@@ -602,6 +619,7 @@ int EngineBase::halo_end(int s, double *array, int nvar, bool unpack, bool on_ha
         hipEventRecord(r.e1, s_comm);
         prof.push_back(r);
     }
+    if (dbg_sync() & 16) HIPCHK(hipStreamSynchronize(s_comm));
     HIPCHK(hipStreamWaitEvent(s_comp, h.ev_done, 0));
     return CMDG_OK;
 }
@@ -649,6 +667,7 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
             prof_ext_done = nullptr;
             prof.push_back(pr);
         }
+        if (dbg_sync() & 64) HIPCHK(hipStreamSynchronize(s_comm));
         HIPCHK(hipStreamWaitEvent(s_comp, EE[evi(pass_seq - 1)], 0));
         return CMDG_OK;
     };
@@ -658,8 +677,10 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
     };
     // exterior launch E_p: waits for I_(p-1)
     auto exterior_begin = [&]() -> int {
-        if (pipe && !(capturing && cap_exterior++ == 0))
+        if (pipe && !(capturing && cap_exterior++ == 0)) {
+            if (dbg_sync() & 64) HIPCHK(hipStreamSynchronize(s_comp));
             HIPCHK(hipStreamWaitEvent(s_comm, EI[evi(pass_seq - 1)], 0));
+        }
         return CMDG_OK;
     };
     auto exterior_end = [&]() -> int {
@@ -773,6 +794,7 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
         if (dsend && c.lsrk) mark_fresh(SLOT_Q, c.Qout, ns);
         // whatever follows on the compute stream (a filter, the caller's next call, the next
         // evaluation's first interior launch) finds this evaluation complete
+        if (pipe && (dbg_sync() & 128)) HIPCHK(hipStreamSynchronize(s_comm));
         if (pipe) HIPCHK(hipStreamWaitEvent(s_comp, EE[evi(pass_seq)], 0));
         if (tendency_filter) TRY(filter_apply(tendency_filter, c.tendency, ns));  // (:417-425)
         if (c.update_after) {
@@ -784,6 +806,7 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
     default: break;
     }
 #undef TRY
+    if (dbg_sync() & 512) HIPCHK(hipDeviceSynchronize());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CMDG_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return CMDG_OK;
@@ -827,6 +850,7 @@ int group_rhs(std::vector<EngineBase *> &g, std::vector<RhsCtx> &c, bool keep_fr
 {
     if (!keep_fresh)
         for (auto *e : g) e->invalidate_sends();
+    if (dbg_sync() & 256) (void)hipDeviceSynchronize();
     for (int s = 0; s < EngineBase::NSEG; ++s)
         for (size_t i = 0; i < g.size(); ++i)
             if (int r = g[i]->rhs_segment(s, c[i])) {

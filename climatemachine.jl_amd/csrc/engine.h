@@ -56,6 +56,14 @@ struct FilterObj {
 // in the process (rocprofv3 --marker-trace) or CMDG_ROCTX=1 asks for it to be loaded
 void roctx_push(const char *name);
 void roctx_pop();
+// CMDG_DBG_SYNC=<bitmask>: localise a missing stream dependency by turning one class of
+// event edges at a time into a host-side hipStreamSynchronize (scripts/probe/priority_order_sweep.sh)
+//   1 order() of the split-explicit steppers   2 halo_pack: compute -> halo stream
+//   4 halo_pack: neighbours' ev_pulled         8 halo_end: neighbours' ev_packed
+//   16 halo_end: ev_done -> compute stream     32 before_direct_send
+//   64 interior_begin / exterior_begin         128 the join at the end of segment 5
+//   256 device synchronize before every group_rhs   512 device synchronize after every segment
+int dbg_sync();
 struct Range {
     explicit Range(const char *name) { roctx_push(name); }
     ~Range() { roctx_pop(); }

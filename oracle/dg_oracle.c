@@ -40,6 +40,25 @@ int orc_get_max_threads(void)
 #endif
 }
 
+/* bench.py's cpu_baseline only.  Copies an (nchunks, chunk_bytes) array with the loop schedule of
+ * the kernels below (static, over elements), so that every thread first touches the pages of the
+ * elements it will work on: on a multi-socket host a numpy-initialised array lives on the NUMA
+ * node of the one thread that filled it. */
+void orc_first_touch_copy(void *dst, const void *src, int64_t nchunks, int64_t chunk_bytes)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < nchunks; ++c)
+        memcpy((char *)dst + c * chunk_bytes, (const char *)src + c * chunk_bytes, (size_t)chunk_bytes);
+}
+
+/* a[i] = b[i] + s * c[i]: one streaming pass (24 B per entry), the host's memory-bandwidth
+ * ceiling next to the cpu_baseline figure */
+void orc_stream_triad(double *a, const double *b, const double *c, double s, int64_t n)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) a[i] = b[i] + s * c[i];
+}
+
 static inline double VG(const orc_grid *g, int ijk, int col, int64_t e)
 {
     return g->vgeo[ijk + (int64_t)g->Np * (col + (int64_t)g->nvgeo * e)];

@@ -98,6 +98,31 @@ def get_max_threads():
     return int(lib().orc_get_max_threads())
 
 
+def first_touch(a):
+    """A copy of ``a`` (leading axis = elements) whose pages are first written by the OpenMP
+    thread that will work on those elements (``orc_first_touch_copy``): bench.py's cpu_baseline."""
+    a = np.ascontiguousarray(a)
+    out = np.empty_like(a)
+    if a.size:
+        lib().orc_first_touch_copy(_p(out), _p(a), C.c_int64(a.shape[0]),
+                                   C.c_int64(a.nbytes // a.shape[0]))
+    return out
+
+
+def stream_triad_gbs(n=1 << 27, repeats=3):
+    """Achieved GB/s of ``a = b + s c`` over first-touched arrays with the threads in use."""
+    import time
+    b = first_touch(np.ones((n // 4096, 4096)))
+    c = first_touch(np.ones((n // 4096, 4096)))
+    a = first_touch(np.zeros((n // 4096, 4096)))
+    best = 0.0
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        lib().orc_stream_triad(_p(a), _p(b), _p(c), C.c_double(0.5), C.c_int64(a.size))
+        best = max(best, 24.0 * a.size / (time.perf_counter() - t0) / 1e9)
+    return best
+
+
 class OracleGrid:
     """Keeps the numpy tables alive and exposes the C ``orc_grid``."""
 
@@ -124,6 +149,14 @@ class OracleGrid:
         self.interior = np.ascontiguousarray(grid.interiorelems, dtype=np.int64)
         self.exterior = np.ascontiguousarray(grid.exteriorelems, dtype=np.int64)
         self.activedofs = np.ascontiguousarray(grid.activedofs, dtype=np.uint8)
+
+    def numa_distribute(self):
+        """Re-home the per-element tables by first touch (bench.py's cpu_baseline)."""
+        for name in ("vgeo", "sgeo", "vmapM", "vmapP", "elemtobndy"):
+            setattr(self, name, first_touch(getattr(self, name)))
+        g = self.c
+        g.vgeo, g.sgeo = _p(self.vgeo), _p(self.sgeo)
+        g.vmapM, g.vmapP, g.elemtobndy = _p(self.vmapM), _p(self.vmapP), _p(self.elemtobndy)
 
 
 class OraclePhysics:
@@ -191,6 +224,12 @@ class OracleDGModel:
         # (callables (dg, Q, t, "real" | "ghost")); None = the nodal default / `false`
         self.update_auxiliary_state_hook = None
         self.update_auxiliary_state_gradient_hook = None
+
+    def numa_distribute(self):
+        """Re-home every per-element array of the operator by first touch (cpu_baseline)."""
+        self.og.numa_distribute()
+        for name in ("state_auxiliary", "state_gradient_flux", "Qhypervisc_grad", "Qhypervisc_div"):
+            setattr(self, name, first_touch(getattr(self, name)))
 
     # -- launchers (SpaceDiscretization.jl) ----------------------------------
     def _dirs(self, d):

@@ -124,3 +124,23 @@ def test_result_line_survives_native_output_on_stdout():
     assert r.returncode == 0, r.stderr
     assert r.stdout.strip().splitlines() == ['{"metric": "x", "value": 1}']
     assert "NCCL WARN something native" in r.stderr and "python chatter" in r.stderr
+
+
+
+def test_cpu_baseline_reports_its_threads_and_memory_ceiling(monkeypatch):
+    """The all-core figure says how many threads it ran on (never more than the affinity mask or
+    the cgroup quota allow), how they were placed, and the streaming bandwidth they reach together
+    (SURVEY 8(d)); its arrays are first-touched by the threads that work on them."""
+    from cmdg_loader import cm
+    info = bench.host_cpu_info()
+    assert info["affinity_threads"] >= 1
+    assert bench.baseline_threads({"affinity_threads": 128, "cgroup_cpu_quota": 16.0}, 128) == 16
+    assert bench.baseline_threads({"affinity_threads": 8, "cgroup_cpu_quota": None}, 128) == 8
+    args = types.SimpleNamespace(workload="advdiff-brick", bomex_ne=16, nvert=8)
+    law, grid, direction, dt, _ = bench.build_workload(cm, "advdiff-brick", 0, 1, 3, args)
+    out = bench.cpu_baseline(cm, law, grid, direction, dt, 0.2, args)
+    assert out["kind"] == "port" and out["value"] > 0
+    assert out["cores"] == out["threads"] == bench.baseline_threads(info, 10 ** 6) or out["threads"] <= info["affinity_threads"]
+    assert out["omp"] == {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")}
+    assert out["omp"]["OMP_PROC_BIND"] is not None      # bench.py sets them before libgomp loads
+    assert out["stream_triad_GBs"] > 0 and "first_touch" in out and out["host"] == info
