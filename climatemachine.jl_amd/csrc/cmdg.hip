@@ -111,6 +111,27 @@ int dbg_sync()
     return v;
 }
 
+unsigned ev_flags()
+{
+    static const unsigned v = [] {
+        const char *p = getenv("CMDG_DBG_EVFLAGS");
+        return (p && !strcmp(p, "timing")) ? 0u : (unsigned)hipEventDisableTiming;
+    }();
+    return v;
+}
+hipError_t ev_record(hipEvent_t &e, hipStream_t s)
+{
+    static const bool ring = [] {
+        const char *p = getenv("CMDG_DBG_EVRING");
+        return p && *p == '1';
+    }();
+    if (ring) {  // (debugging only: the replaced events are leaked)
+        hipEvent_t n = nullptr;
+        if (hipEventCreateWithFlags(&n, ev_flags()) == hipSuccess) e = n;
+    }
+    return hipEventRecord(e, s);
+}
+
 // ---------------------------------------------------------------------------------
 EngineBase::~EngineBase()
 {
@@ -130,6 +151,8 @@ EngineBase::~EngineBase()
     if (W[0]) hipFree(W[0]);
     if (W[1]) hipFree(W[1]);
     if (d_D) hipFree(d_D);
+    if (d_pairs[0]) hipFree(d_pairs[0]);
+    if (d_pairs[1]) hipFree(d_pairs[1]);
     if (d_interior_tiled) hipFree(d_interior_tiled);
     if (d_exterior_tiled) hipFree(d_exterior_tiled);
     if (d_faceP) hipFree(d_faceP);
@@ -228,12 +251,12 @@ int EngineBase::init(const cmdg_desc *d)
             HIPCHK(hipStreamCreateWithFlags(&s_comm, hipStreamNonBlocking));
     }
     for (int i = 0; i < 2; ++i) {
-        HIPCHK(hipEventCreateWithFlags(&ev_int[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ev_ext[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_int[i], ev_flags()));
+        HIPCHK(hipEventCreateWithFlags(&ev_ext[i], ev_flags()));
     }
-    HIPCHK(hipEventCreateWithFlags(&gev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&gev_fork, ev_flags()));
     if (const char *v = getenv("CMDG_STEP_GRAPH")) step_graph = *v && *v != '0';
-    HIPCHK(hipEventCreateWithFlags(&ev_comp, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_comp, ev_flags()));
     HIPCHK(hipMalloc(&d_D, sizeof(double) * NQ * NQ));
     HIPCHK(hipMemcpy(d_D, d->D, sizeof(double) * NQ * NQ, hipMemcpyHostToDevice));
     g.D = d_D;
@@ -251,7 +274,7 @@ int EngineBase::init(const cmdg_desc *d)
         HIPCHK(hipMalloc(&d_faceP, sizeof(int32_t) * nt));
         HIPCHK(hipMalloc(&d_faceG, sizeof(double) * 4 * nt));
         HIPCHK(hipMalloc(&d_bad, sizeof(int)));
-        HIPCHK(hipMemset(d_bad, 0, sizeof(int)));
+        HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), s_comp));  // (stream-ordered before the digest, see alloc0)
         if (nreal > 0)
             hipLaunchKernelGGL(k_face_digest, dim3((unsigned)((nreal * NFT + 255) / 256)), dim3(256), 0,
                                s_comp, g.vgeo, g.nvgeo, g.sgeo, g.vmapM, g.vmapP, g.elemtobndy, NQ,
@@ -273,10 +296,13 @@ int EngineBase::init(const cmdg_desc *d)
     }
     aux = d->state_auxiliary;
     const size_t nd = (size_t)Np * nelem;
+    // hipMemset of device memory returns before the fill has run, and on the null stream it is not
+    // ordered against this engine's non-blocking streams (scripts/probe/memset_null_stream_order.py):
+    // every fill is enqueued on the compute stream, which init() drains before it returns
     auto alloc0 = [&](double **p, size_t n) -> int {
         if (n == 0) n = 1;
         HIPCHK(hipMalloc(p, sizeof(double) * n));
-        HIPCHK(hipMemset(*p, 0, sizeof(double) * n));
+        HIPCHK(hipMemsetAsync(*p, 0, sizeof(double) * n, s_comp));
         return CMDG_OK;
     };
     gf = d->state_gradient_flux;
@@ -299,9 +325,9 @@ int EngineBase::init(const cmdg_desc *d)
         for (auto &s : slot) {
             HIPCHK(hipMalloc(&s.sendbuf, sizeof(double) * slot_nvar_max * std::max<int64_t>(nvmapsend, 1)));
             HIPCHK(hipMalloc(&s.recvbuf, sizeof(double) * slot_nvar_max * std::max<int64_t>(nvmaprecv, 1)));
-            HIPCHK(hipEventCreateWithFlags(&s.ev_packed, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&s.ev_pulled, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&s.ev_packed, ev_flags()));
+            HIPCHK(hipEventCreateWithFlags(&s.ev_done, ev_flags()));
+            HIPCHK(hipEventCreateWithFlags(&s.ev_pulled, ev_flags()));
         }
     }
     HIPCHK(hipMalloc(&d_partial, sizeof(double) * 1024));
@@ -310,7 +336,32 @@ int EngineBase::init(const cmdg_desc *d)
     // debugging overrides of the two exchange options (cmdg_set_option still has the last word)
     if (const char *v = getenv("CMDG_REFERENCE_HALO")) reference_halo = *v && *v != '0';
     if (const char *v = getenv("CMDG_HALO_PIPELINE")) no_pipeline = *v == '0';
-    return init_derived();
+    if (const char *v = getenv("CMDG_TENDENCY_PAIRS")) tendency_pairs = *v && *v != '0';
+    if (int r = build_pairs()) return r;
+    if (int r = init_derived()) return r;
+    HIPCHK(hipStreamSynchronize(s_comp));  // the fills of alloc0 have run
+    // CMDG_DBG_INIT=<bitmask> (localising the first-use failure of priority halo streams):
+    //   1 prime both streams (a memset node each, then wait)   2 zero the halo buffers
+    //   4 allocate the LSRK work states now                     8 device-wide synchronize
+    static const int dbg_init = [] {
+        const char *p = getenv("CMDG_DBG_INIT");
+        return p ? atoi(p) : 0;
+    }();
+    if (dbg_init & 1) {
+        HIPCHK(hipMemsetAsync(d_partial, 0, 8, s_comp));
+        HIPCHK(hipMemsetAsync(d_partial + 8, 0, 8, s_comm));
+        HIPCHK(hipStreamSynchronize(s_comp));
+        HIPCHK(hipStreamSynchronize(s_comm));
+    }
+    if ((dbg_init & 2) && communicate())
+        for (auto &sl : slot) {
+            HIPCHK(hipMemset(sl.sendbuf, 0, sizeof(double) * slot_nvar_max * std::max<int64_t>(nvmapsend, 1)));
+            HIPCHK(hipMemset(sl.recvbuf, 0, sizeof(double) * slot_nvar_max * std::max<int64_t>(nvmaprecv, 1)));
+        }
+    if (dbg_init & 4)
+        if (int r = ensure_work()) return r;
+    if (dbg_init & 8) HIPCHK(hipDeviceSynchronize());
+    return CMDG_OK;
 }
 
 // Tables of the exchange without pack / unpack launches (HaloDev).  Whatever cannot be built
@@ -386,8 +437,23 @@ int EngineBase::ensure_work()
     for (int i = 0; i < 2; ++i)
         if (!W[i]) {
             const size_t n = (size_t)Np * ns * nelem;
+            // Allocated inside the first step, while the step's launches are being enqueued: the
+            // fill must be ordered before them.  Until round 4 this was a hipMemset -- asynchronous
+            // for device memory and, on the null stream, unordered against the non-blocking
+            // streams below, so it could land AFTER the first stages had stored into W and zero
+            // them (the "priority stream ordering failure" of round 3: high-priority halo streams
+            // merely let the stage kernels overtake the fill; CMDG_DBG_WORK_MEMSET=null restores it).
             HIPCHK(hipMalloc(&W[i], sizeof(double) * n));
-            HIPCHK(hipMemset(W[i], 0, sizeof(double) * n));
+            static const bool legacy = [] {
+                const char *p = getenv("CMDG_DBG_WORK_MEMSET");
+                return p && !strcmp(p, "null");
+            }();
+            if (legacy) {
+                HIPCHK(hipMemset(W[i], 0, sizeof(double) * n));
+            } else {
+                HIPCHK(hipMemsetAsync(W[i], 0, sizeof(double) * n, s_comp));
+                HIPCHK(hipStreamSynchronize(s_comp));
+            }
         }
     return CMDG_OK;
 }
@@ -461,7 +527,7 @@ int EngineBase::halo_pack(int s, double *array, int nvar, int ncol, bool on_halo
         return fail(CMDG_ERR_UNSUPPORTED, "step graph: an exchange of this step would have to be packed");
     if (!(fresh && on_halo_stream)) {
         if (dbg_sync() & 2) HIPCHK(hipStreamSynchronize(s_comp));
-        HIPCHK(hipEventRecord(ev_comp, s_comp));
+        HIPCHK(ev_record(ev_comp, s_comp));
         HIPCHK(hipStreamWaitEvent(s_comm, ev_comp, 0));
     }
     if (transport == TRANSPORT_LOCAL) {
@@ -478,7 +544,7 @@ int EngineBase::halo_pack(int s, double *array, int nvar, int ncol, bool on_halo
                            h.sendbuf, array, d_vmapsend, nvmapsend, Np, nvar, ncol);
         prof_end(s_comm);
     }
-    if (!capturing) HIPCHK(hipEventRecord(h.ev_packed, s_comm));  // (read by the local transport only)
+    if (!capturing) HIPCHK(ev_record(h.ev_packed, s_comm));  // (read by the local transport only)
     return CMDG_OK;
 }
 
@@ -542,7 +608,7 @@ int EngineBase::set_stack_height(int nv)
     HIPCHK(hipStreamSynchronize(s_comp));
     d_interior = d_interior_user;
     d_exterior = d_exterior_user;
-    if (nv < MIN_HEIGHT) return CMDG_OK;
+    if (nv < MIN_HEIGHT) return build_pairs();
     for (int which = 0; which < 2; ++which) {
         const int64_t n = which ? nexterior : ninterior;
         if (n == 0) continue;
@@ -558,6 +624,99 @@ int EngineBase::set_stack_height(int nv)
         if (!own) HIPCHK(hipMalloc(&own, sizeof(int64_t) * n));
         HIPCHK(hipMemcpy(own, h.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice));
         (which ? d_exterior : d_interior) = own;
+    }
+    return build_pairs();
+}
+
+// CMDG_OPT_STREAM_PRIORITY: both streams of the handle at the highest (1) or the default (0)
+// priority.  For a handle whose launches are small and form a long dependent chain next to another
+// handle's bandwidth-bound launches -- the barotropic model of the split-explicit ocean -- the
+// dispatcher then takes its work-groups first whenever a slot frees up.
+int EngineBase::set_stream_priority(int level)
+{
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (level != 0 && level != 1) return fail(CMDG_ERR_INVALID, "stream priority: 0 (default) or 1 (highest)");
+    if (int r = synchronize()) return r;
+    drop_graph();
+    hipStream_t nc = nullptr, nm = nullptr;
+    const int prio = level ? hi : 0;
+    HIPCHK(hipStreamCreateWithPriority(&nc, hipStreamNonBlocking, prio));
+    HIPCHK(hipStreamCreateWithPriority(&nm, hipStreamNonBlocking, prio));
+    hipStreamDestroy(s_comp);
+    hipStreamDestroy(s_comm);
+    s_comp = nc;
+    s_comm = nm;
+    stream_priority = level;
+    return CMDG_OK;
+}
+
+// Pair lists of the tendency pass (TendencyShape<..., PAIR>): walk each element list in its launch
+// order and give every element its xi1+ neighbour (else its xi1- neighbour) as a partner when the
+// two faces match node for node, both are real elements of the same list and neither is taken;
+// what is left over shares work-groups two by two without a shared face.
+int EngineBase::build_pairs()
+{
+    for (int w = 0; w < 2; ++w) {
+        if (d_pairs[w]) hipFree(d_pairs[w]);
+        d_pairs[w] = nullptr;
+        npairs[w] = nshared[w] = 0;
+    }
+    if (!tendency_pairs || !law_pairable() || nreal == 0) return CMDG_OK;
+    const int Nfph = NQ * NQV, NFT = 4 * Nfph + 2 * NQ * NQ;
+    std::vector<int32_t> fP((size_t)nreal * NFT);
+    HIPCHK(hipMemcpy(fP.data(), d_faceP, sizeof(int32_t) * fP.size(), hipMemcpyDeviceToHost));
+    auto vid = [&](int f, int n) {  // face_vid of kernels.h, faces 1 and 2 only
+        const int a = n % NQ, b = n / NQ;
+        return f == 0 ? NQ * (a + NQ * b) : (NQ - 1) + NQ * (a + NQ * b);
+    };
+    // the element across face f of e whose face f^1 meets it node for node, -1: none
+    auto across = [&](int64_t e, int f) -> int64_t {
+        int64_t cand = -1;
+        for (int n = 0; n < Nfph; ++n) {
+            const int64_t id = fP[(size_t)e * NFT + f * Nfph + n], eP = id / Np;
+            if (n == 0) cand = eP;
+            if (eP != cand || id - eP * Np != vid(f ^ 1, n)) return -1;
+        }
+        if (cand == e || cand >= nreal) return -1;
+        for (int n = 0; n < Nfph; ++n)  // (and back)
+            if (fP[(size_t)cand * NFT + (f ^ 1) * Nfph + n] != e * Np + vid(f, n)) return -1;
+        return cand;
+    };
+    std::vector<int32_t> where((size_t)nreal);
+    for (int w = 0; w < 2; ++w) {
+        const int64_t n = w ? nexterior : ninterior;
+        if (n == 0) continue;
+        std::vector<int64_t> h((size_t)n), out, single;
+        HIPCHK(hipMemcpy(h.data(), w ? d_exterior : d_interior, sizeof(int64_t) * n, hipMemcpyDeviceToHost));
+        std::fill(where.begin(), where.end(), -1);
+        for (int64_t i = 0; i < n; ++i) where[h[i] - 1] = (int32_t)i;
+        std::vector<uint8_t> used((size_t)n, 0);
+        out.reserve((size_t)n + 2);
+        for (int64_t i = 0; i < n; ++i) {
+            if (used[i]) continue;
+            const int64_t e = h[i] - 1;
+            used[i] = 1;
+            const int64_t ep = across(e, 1), em = across(e, 0);
+            if (ep >= 0 && where[ep] >= 0 && !used[where[ep]]) {
+                used[where[ep]] = 1;
+                out.push_back(e + 1), out.push_back(ep + 1);
+                nshared[w] += 1;
+            } else if (em >= 0 && where[em] >= 0 && !used[where[em]]) {
+                used[where[em]] = 1;
+                out.push_back(em + 1), out.push_back(e + 1);
+                nshared[w] += 1;
+            } else {
+                single.push_back(e + 1);
+            }
+        }
+        for (size_t q = 0; q < single.size(); q += 2) {
+            out.push_back(single[q]);
+            out.push_back(q + 1 < single.size() ? -single[q + 1] : 0);
+        }
+        npairs[w] = (int64_t)out.size() / 2;
+        HIPCHK(hipMalloc(&d_pairs[w], sizeof(int64_t) * out.size()));
+        HIPCHK(hipMemcpy(d_pairs[w], out.data(), sizeof(int64_t) * out.size(), hipMemcpyHostToDevice));
     }
     return CMDG_OK;
 }
@@ -596,7 +755,7 @@ int EngineBase::halo_end(int s, double *array, int nvar, bool unpack, bool on_ha
                                   sizeof(double) * rn * nvar, hipMemcpyDeviceToDevice, s_comm));
         }
         if (!nabrtorank.empty()) prof_end(s_comm);
-        HIPCHK(hipEventRecord(h.ev_pulled, s_comm));
+        HIPCHK(ev_record(h.ev_pulled, s_comm));
     }
     if (nvmaprecv > 0 && unpack) {
         const int64_t n = nvmaprecv * nvar;
@@ -606,7 +765,7 @@ int EngineBase::halo_end(int s, double *array, int nvar, bool unpack, bool on_ha
         prof_end(s_comm);
     }
     if (on_halo_stream) return CMDG_OK;  // the consumer is the next launch of the halo stream
-    HIPCHK(hipEventRecord(h.ev_done, s_comm));
+    HIPCHK(ev_record(h.ev_done, s_comm));
     if (profiling) {
         // exposed time of this exchange: from the moment the compute stream has nothing left to
         // do but wait (its interior launches are done) to the moment the ghosts are in place
@@ -672,7 +831,7 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
         return CMDG_OK;
     };
     auto interior_end = [&]() -> int {
-        if (pipe) HIPCHK(hipEventRecord(EI[evi(pass_seq)], s_comp));
+        if (pipe) HIPCHK(ev_record(EI[evi(pass_seq)], s_comp));
         return CMDG_OK;
     };
     // exterior launch E_p: waits for I_(p-1)
@@ -684,7 +843,7 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
         return CMDG_OK;
     };
     auto exterior_end = [&]() -> int {
-        if (pipe) HIPCHK(hipEventRecord(EE[evi(pass_seq)], s_comm));
+        if (pipe) HIPCHK(ev_record(EE[evi(pass_seq)], s_comm));
         if (pipe && profiling) {
             if (prof_ext_done) hipEventDestroy(prof_ext_done);
             hipEventCreate(&prof_ext_done);
@@ -934,11 +1093,16 @@ __global__ void k_step_times(double *g, int nstages)
 bool EngineBase::graph_eligible() const
 {
     const bool comm = communicate() && !(stacked && direction == DIR_VERTICAL);
-    // Handles that exchange stay eager: with ncclSend / ncclRecv groups recorded on the halo stream
-    // (RCCL 2.26.6, ROCm 7.0.2, a rank as its own neighbour) hipStreamEndCapture crashes; the same
-    // two-stream capture with device copies in place of the groups instantiates and replays.
+    // A handle that exchanges can be recorded when its exchanges need neither a pack nor an unpack
+    // launch from the compute stream (pipelined()) and travel through RCCL.  The groups must then sit
+    // on the capture's ORIGIN stream: on HIP 7.0.2 / RCCL 2.26.6 (the stack torch brings) a group
+    // recorded on a stream that joined the capture through an event crashes hipStreamEndCapture,
+    // whatever the capture mode; on ROCm 7.2 / RCCL 2.27.7 both forms work
+    // (scripts/probe/rccl_capture_probe.py, profiles/r04_rccl_capture_probes.txt).  The halo stream
+    // is therefore the origin of such a capture and the compute stream the forked one.
+    const bool comm_ok = !comm || (transport == TRANSPORT_RCCL && pipelined(comm));
     return step_graph && !graph_failed && !profiling && !step_filter && !tendency_filter &&
-           !gradient_filter && !has_hooks && (!has_update_aux() || fused_update_aux()) && !comm;
+           !gradient_filter && !has_hooks && (!has_update_aux() || fused_update_aux()) && comm_ok;
 }
 
 int EngineBase::capture_step(double *Q, double *dQ, double dt, int nstages, const double *rka,
@@ -954,25 +1118,32 @@ int EngineBase::capture_step(double *Q, double *dQ, double dt, int nstages, cons
     double *Qs[1] = {Q}, *dQs[1] = {dQ};
     if (4 * nstages + 1 > NGEV) return fail(CMDG_ERR_UNSUPPORTED, "step graph: too many stages");
     for (int i = 0; i < NGEV; ++i) {  // (created on first use: most handles never capture)
-        if (!gev_int[i]) HIPCHK(hipEventCreateWithFlags(&gev_int[i], hipEventDisableTiming));
-        if (!gev_ext[i]) HIPCHK(hipEventCreateWithFlags(&gev_ext[i], hipEventDisableTiming));
+        if (!gev_int[i]) HIPCHK(hipEventCreateWithFlags(&gev_int[i], ev_flags()));
+        if (!gev_ext[i]) HIPCHK(hipEventCreateWithFlags(&gev_ext[i], ev_flags()));
     }
     capturing = true;
     cap_interior = cap_exterior = cap_pass = 0;
     hipGraph_t graph = nullptr;
     int r = CMDG_OK;
-    if (hipStreamBeginCapture(s_comp, hipStreamCaptureModeRelaxed) != hipSuccess) {
+    // origin of the capture: the stream the RCCL groups are recorded on (graph_eligible)
+    const hipStream_t so = comm ? s_comm : s_comp;
+    if (hipStreamBeginCapture(so, hipStreamCaptureModeRelaxed) != hipSuccess) {
         capturing = false;
         return fail(CMDG_ERR_HIP, "step graph: hipStreamBeginCapture failed");
     }
-    hipLaunchKernelGGL(k_step_times, dim3(1), dim3(1), 0, s_comp, d_gtime, nstages);
-    if (comm) {  // the halo stream joins the capture
-        if (hipEventRecord(gev_fork, s_comp) != hipSuccess ||
-            hipStreamWaitEvent(s_comm, gev_fork, 0) != hipSuccess)
-            r = fail(CMDG_ERR_HIP, "step graph: fork of the halo stream failed");
+    hipLaunchKernelGGL(k_step_times, dim3(1), dim3(1), 0, so, d_gtime, nstages);
+    if (comm) {  // the compute stream joins the capture
+        if (hipEventRecord(gev_fork, s_comm) != hipSuccess ||
+            hipStreamWaitEvent(s_comp, gev_fork, 0) != hipSuccess)
+            r = fail(CMDG_ERR_HIP, "step graph: fork of the compute stream failed");
     }
     if (!r) r = group_lsrk_step(one, Qs, dQs, 0.0, dt, nstages, rka, rkb, rkc, true, d_gtime + 2);
-    const hipError_t ee = hipStreamEndCapture(s_comp, &graph);
+    if (comm && !r) {  // ... and ends in the origin stream
+        if (hipEventRecord(gev_fork, s_comp) != hipSuccess ||
+            hipStreamWaitEvent(s_comm, gev_fork, 0) != hipSuccess)
+            r = fail(CMDG_ERR_HIP, "step graph: join of the compute stream failed");
+    }
+    const hipError_t ee = hipStreamEndCapture(so, &graph);
     capturing = false;
     if (r || ee != hipSuccess || !graph) {
         if (graph) hipGraphDestroy(graph);
@@ -1014,10 +1185,19 @@ int EngineBase::run_steps(double *Q, double *dQ, double t, double dt, int64_t ns
             StepTimesInit v{};
             v.t_next = t, v.dt = dt, v.nstages = nstages;
             for (int s = 0; s < nstages; ++s) v.rkc[s] = rkc[s];
-            hipLaunchKernelGGL(k_step_times_init, dim3(1), dim3(1), 0, s_comp, d_gtime, v);
+            const hipStream_t so = key.comm ? s_comm : s_comp;
+            if (key.comm) {  // the eager step's work on the compute stream comes first
+                HIPCHK(hipEventRecord(ev_comp, s_comp));
+                HIPCHK(hipStreamWaitEvent(s_comm, ev_comp, 0));
+            }
+            hipLaunchKernelGGL(k_step_times_init, dim3(1), dim3(1), 0, so, d_gtime, v);
             for (; i < nsteps; ++i, t += dt) {
-                HIPCHK(hipGraphLaunch(graph_exec, s_comp));
+                HIPCHK(hipGraphLaunch(graph_exec, so));
                 graph_steps += 1;
+            }
+            if (key.comm) {  // whatever the caller enqueues next on the compute stream follows the run
+                HIPCHK(hipEventRecord(ev_comp, s_comm));
+                HIPCHK(hipStreamWaitEvent(s_comp, ev_comp, 0));
             }
             return CMDG_OK;
         }
@@ -1146,6 +1326,7 @@ int EngineBase::set_hooks(const cmdg_rhs_hooks *hk)
     if (!hk) {
         forget_child();
         has_hooks = false;
+        hooks_orphaned = false;
         hooks.pre_rhs_handle = nullptr;
         return CMDG_OK;
     }
@@ -1192,19 +1373,22 @@ int EngineBase::set_hooks(const cmdg_rhs_hooks *hk)
     hooks = *hk;
     hooks.Imat = nullptr;
     has_hooks = true;
+    hooks_orphaned = false;
     if (hooks.pre_rhs_handle) hooks.pre_rhs_handle->eng->nested_in.push_back(this);
     return CMDG_OK;
 }
 
 int EngineBase::run_pre_hooks(const RhsCtx &c)
 {
+    if (hooks_orphaned)
+        return fail(CMDG_ERR_INVALID, "hooks: the nested operator of this handle was destroyed; set new hooks");
     for (int i = 0; i < hooks.npre; ++i)
         if (int r = filter_apply(reinterpret_cast<const FilterObj *>(hooks.pre_filter[i]), c.Qin, ns))
             return r;
     if (hooks.pre_rhs_handle) {
         // conti3d_dg(ct3d_dQ, Q, p, t; increment = false); A.w = dQ.theta  (OceanModel.jl:456-477)
         EngineBase *ch = hooks.pre_rhs_handle->eng;
-        HIPCHK(hipEventRecord(ev_comp, s_comp));
+        HIPCHK(ev_record(ev_comp, s_comp));
         HIPCHK(hipStreamWaitEvent(ch->s_comp, ev_comp, 0));
         RhsCtx cc;
         cc.tendency = d_preT;
@@ -1213,7 +1397,7 @@ int EngineBase::run_pre_hooks(const RhsCtx &c)
         cc.alpha = 1.0;
         cc.beta = 0.0;
         if (int r = ch->rhs_async(cc)) return fail(r, "nested operator: " + ch->err);
-        HIPCHK(hipEventRecord(ch->ev_comp, ch->s_comp));
+        HIPCHK(ev_record(ch->ev_comp, ch->s_comp));
         HIPCHK(hipStreamWaitEvent(s_comp, ch->ev_comp, 0));
         const int64_t n = nreal * Np;
         hipLaunchKernelGGL(k_scaled_column_copy, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)),
@@ -1559,11 +1743,14 @@ int cmdg_destroy(cmdg_handle h)
     if (!h) return CMDG_ERR_INVALID;
     {
         DevGuard guard_(h->eng);
-        // handles whose hooks evaluate this one as their nested operator go on without it, and
-        // the nested operator of this handle forgets its parent
+        // handles whose hooks evaluate this one as their nested operator cannot evaluate any more
+        // (they would compute something else than the law they were given): their next evaluation
+        // fails until cmdg_set_rhs_hooks gives them new hooks; the nested operator of this handle
+        // forgets its parent
         for (EngineBase *parent : h->eng->nested_in) {
             parent->synchronize();
             parent->hooks.pre_rhs_handle = nullptr;
+            parent->hooks_orphaned = true;
         }
         if (h->eng->has_hooks && h->eng->hooks.pre_rhs_handle && h->eng->hooks.pre_rhs_handle->eng) {
             auto &v = h->eng->hooks.pre_rhs_handle->eng->nested_in;
@@ -1637,20 +1824,34 @@ int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value)
     DevGuard guard_(h->eng);
     EngineBase *e = h->eng;
     switch (option) {
-    case CMDG_OPT_KEEP_GRADFLUX: e->keep_gradflux = value != 0; return CMDG_OK;
-    case CMDG_OPT_STACK_HEIGHT: return set_err(h, e->set_stack_height(value));
+    case CMDG_OPT_KEEP_GRADFLUX:
+        e->drop_graph();
+        e->keep_gradflux = value != 0;
+        return CMDG_OK;
+    case CMDG_OPT_STACK_HEIGHT:
+        e->drop_graph();
+        return set_err(h, e->set_stack_height(value));
     case CMDG_OPT_REFERENCE_HALO:
         if (int r = e->synchronize()) return set_err(h, r);
+        e->drop_graph();
         e->reference_halo = value != 0;
         e->invalidate_sends();
         return CMDG_OK;
     case CMDG_OPT_STEP_GRAPH:
         if (int r = e->synchronize()) return set_err(h, r);
+        e->drop_graph();
         e->step_graph = value != 0;
         e->graph_failed = false;
         return CMDG_OK;
+    case CMDG_OPT_STREAM_PRIORITY: return set_err(h, e->set_stream_priority(value));
+    case CMDG_OPT_TENDENCY_PAIRS:
+        if (int r = e->synchronize()) return set_err(h, r);
+        e->drop_graph();
+        e->tendency_pairs = value != 0;
+        return set_err(h, e->build_pairs());
     case CMDG_OPT_HALO_PIPELINE:
         if (int r = e->synchronize()) return set_err(h, r);
+        e->drop_graph();
         e->no_pipeline = value == 0;
         e->invalidate_sends();
         return CMDG_OK;
@@ -1672,6 +1873,7 @@ int cmdg_query(cmdg_handle h, int32_t what, int64_t *out)
     case CMDG_Q_DIRECT_RECV: *out = e->communicate() && e->direct_recv(); return CMDG_OK;
     case CMDG_Q_TENDENCY_ELEMS_PER_GROUP: *out = e->tendency_epb(); return CMDG_OK;
     case CMDG_Q_GRAPH_STEPS: *out = e->graph_steps; return CMDG_OK;
+    case CMDG_Q_TENDENCY_PAIRS: *out = e->d_pairs[0] || e->d_pairs[1] ? e->nshared[0] + e->nshared[1] : -1; return CMDG_OK;
     case CMDG_Q_HOST_POST_NS: *out = e->host_post_ns; return CMDG_OK;
     case CMDG_Q_HOST_POST_COUNT: *out = e->host_post_n; return CMDG_OK;
     case CMDG_Q_HALO_PIPELINE:
@@ -1971,6 +2173,7 @@ int cmdg_set_filters(cmdg_handle h, cmdg_filter gradient_filter, cmdg_filter ten
     // filters decide which streams the next evaluation's launches go to: start it from a clean slate
     if (int r = e->synchronize()) return set_err(h, r);
     e->invalidate_sends();
+    e->drop_graph();
     e->gradient_filter = gfl;
     e->tendency_filter = tfl;
     e->step_filter = reinterpret_cast<FilterObj *>(step_filter);
@@ -1983,6 +2186,7 @@ int cmdg_set_rhs_hooks(cmdg_handle h, const cmdg_rhs_hooks *hooks)
     DevGuard guard_(h->eng);
     if (int r = h->eng->synchronize()) return set_err(h, r);  // (hooks change the stream layout too)
     h->eng->invalidate_sends();
+    h->eng->drop_graph();
     return set_err(h, h->eng->set_hooks(hooks));
 }
 
@@ -1990,6 +2194,7 @@ int cmdg_profile_enable(cmdg_handle h, int32_t on)
 {
     if (!h) return CMDG_ERR_INVALID;
     DevGuard guard_(h->eng);
+    h->eng->drop_graph();
     h->eng->profiling = on != 0;
     return CMDG_OK;
 }

@@ -64,6 +64,10 @@ void roctx_pop();
 //   64 interior_begin / exterior_begin         128 the join at the end of segment 5
 //   256 device synchronize before every group_rhs   512 device synchronize after every segment
 int dbg_sync();
+// CMDG_DBG_EVRING=1: every record takes a fresh event (never re-recorded);
+// CMDG_DBG_EVFLAGS=timing: events are created without hipEventDisableTiming
+hipError_t ev_record(hipEvent_t &e, hipStream_t s);
+unsigned ev_flags();
 struct Range {
     explicit Range(const char *name) { roctx_push(name); }
     ~Range() { roctx_pop(); }
@@ -89,6 +93,17 @@ struct EngineBase {
     const int64_t *d_interior_user = nullptr, *d_exterior_user = nullptr;
     int64_t *d_interior_tiled = nullptr, *d_exterior_tiled = nullptr;
     int set_stack_height(int nv);
+    int set_stream_priority(int level);  // CMDG_OPT_STREAM_PRIORITY
+    int stream_priority = 0;
+    // CMDG_OPT_TENDENCY_PAIRS: the tendency pass takes horizontally adjacent elements two to a
+    // work-group and keeps the xi1 face they share on chip (TendencyShape<..., PAIR>, kernels.h);
+    // the lists: (e0, e1) 1-based per work-group, e1 < 0 unrelated, 0 none
+    bool tendency_pairs = false;
+    int64_t *d_pairs[2] = {nullptr, nullptr};  // interior, exterior
+    int64_t npairs[2] = {0, 0};                // work-groups
+    int64_t nshared[2] = {0, 0};               // ... of which share a face
+    int build_pairs();
+    virtual bool law_pairable() const = 0;
     int64_t ninterior = 0, nexterior = 0;
     const uint8_t *d_activedofs = nullptr;
     double *d_D = nullptr;
@@ -264,6 +279,16 @@ struct EngineBase {
     int64_t graph_steps = 0;        // steps replayed from the graph (cmdg_query)
     bool graph_failed = false;      // a capture failed: this handle stays eager
     bool graph_eligible() const;
+    // whatever changes the launches of an evaluation (options, filters, hooks, profiling) makes a
+    // recorded step stale: the next run records again
+    void drop_graph()
+    {
+        if (graph_exec) {
+            hipStreamSynchronize(s_comp);
+            hipGraphExecDestroy(graph_exec);
+            graph_exec = nullptr;
+        }
+    }
     int capture_step(double *Q, double *dQ, double dt, int nstages, const double *rka,
                      const double *rkb, const double *rkc);
     int run_steps(double *Q, double *dQ, double t, double dt, int64_t nsteps, int nstages,
@@ -295,6 +320,8 @@ struct EngineBase {
                        int nvert, const double *Imat_host, const cmdg_stack_integral_desc *d,
                        int64_t h0 = 0, int64_t nh = -1);
     bool has_hooks = false;
+    // the nested operator of the hooks was destroyed: evaluations fail until new hooks are set
+    bool hooks_orphaned = false;
     cmdg_rhs_hooks hooks{};
     // handles whose hooks evaluate this one as their nested operator (hooks.pre_rhs_handle):
     // cmdg_destroy of this handle detaches it from them
@@ -436,11 +463,47 @@ struct EngineT : EngineBase {
         const bool gfl = P::needs_gradflux(prm);
 #endif
         using SH = TendencyShape<P, NQ_, NQV_>;
-        const dim3 grid((unsigned)SH::blocks(n)), block(SH::NT);
         PassArgs<P> args = make_args(c, elems, n, direction);
         args.h = halo_dev(exterior, c.lsrk ? slot[SLOT_Q].sendbuf : nullptr, nullptr);
         const bool recv = args.h.ghostslot != nullptr && exterior;  // (interior elements have no ghost neighbour)
         if (!recv) args.h.ghostslot = nullptr;
+        if constexpr (SH::PAIRABLE) {
+            const int w = elems == d_exterior ? 1 : 0;
+            if (tendency_pairs && d_pairs[w] && (elems == d_interior || elems == d_exterior)) {
+                using SP = TendencyShape<P, NQ_, NQV_, true>;
+                args.elems = d_pairs[w];
+                args.nelems = 2 * npairs[w];
+                const dim3 pgrid((unsigned)npairs[w]), pblock(SP::NT);
+#define CMDG_TENDP(L, G)                                                                              \
+    do {                                                                                              \
+        if constexpr (KDims<NQ_, NQV_>::Np <= 125) {                                                  \
+            constexpr size_t lds = sizeof(double) * TendencyLds<P, NQ_, NQV_, G, true>::doubles;      \
+            if (recv)                                                                                 \
+                hipLaunchKernelGGL((k_tendency_pair_small<P, NQ_, NQV_, L, G, true>), pgrid, pblock,  \
+                                   lds, st, args);                                                    \
+            else                                                                                      \
+                hipLaunchKernelGGL((k_tendency_pair_small<P, NQ_, NQV_, L, G, false>), pgrid, pblock, \
+                                   lds, st, args);                                                    \
+        } else if (recv)                                                                              \
+            hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, L, G, true, TEND_FUSED, true>), pgrid,       \
+                               pblock, 0, st, args);                                                  \
+        else                                                                                          \
+            hipLaunchKernelGGL((k_tendency<P, NQ_, NQV_, L, G, false, TEND_FUSED, true>), pgrid,      \
+                               pblock, 0, st, args);                                                  \
+    } while (0)
+                if (c.lsrk) {
+                    if (gfl) CMDG_TENDP(true, true);
+                    else CMDG_TENDP(true, false);
+                } else {
+                    if (gfl) CMDG_TENDP(false, true);
+                    else CMDG_TENDP(false, false);
+                }
+#undef CMDG_TENDP
+                prof_end(st);
+                return;
+            }
+        }
+        const dim3 grid((unsigned)SH::blocks(n)), block(SH::NT);
         // large elements: volume half, then interface half + update (TendencyShape::SPLIT)
 #define CMDG_TEND(L, G)                                                                             \
     do {                                                                                            \
@@ -499,6 +562,7 @@ struct EngineT : EngineBase {
     int law_nder() const override { return P::HAS_SOURCE ? P::NDER : 0; }
     int law_nupd() const override { return P::HAS_UPDATE_AUX ? P::NUPD : 0; }
     int tendency_epb() const override { return TendencyShape<P, NQ_, NQV_>::EPB; }
+    bool law_pairable() const override { return TendencyShape<P, NQ_, NQV_>::PAIRABLE; }
     int law_state_read(int pass) const override { return law_reads<P>::state(pass); }
     int law_aux_read(int pass) const override { return law_reads<P>::aux(pass); }
     int init_derived() override

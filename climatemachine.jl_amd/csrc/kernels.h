@@ -364,15 +364,28 @@ struct grad_min_waves<P, std::void_t<decltype(P::GRAD_MIN_WAVES)>> : std::integr
 // still needs 167-181 VGPRs and 73 KB of LDS (two six-wave work-groups per CU at best, no more
 // waves than the fused kernel's eleven), and the round trip of the tendency comes on top.  Kept
 // behind CMDG_TEND_SPLIT_LARGE as the recorded loser.
+//
+// PAIR (round 4, the structural experiment): the two elements of a work-group are horizontal
+// neighbours across a xi1 face -- element 0's face 2 (xi1+) is element 1's face 1 (xi1-), node for
+// node -- and that face never goes to memory: its plus side is the partner's staged minus side
+// (state out of sQ, face fields out of sM or, for large elements, out of the face-plane buffer sP).
+// The xi1 faces are the expensive gathers (stride Nq doubles: every line of the neighbour's column
+// is touched for one value in Nq), so a pair removes 1/2 of them.  The host builds the pair lists
+// at create (EngineBase::build_pairs): entries (e0, e1) 1-based, e1 < 0 for two unrelated elements
+// sharing a work-group, 0 for none.  Small elements keep the minus side staged (two 192-thread
+// halves, wave aligned); large ones read it from memory as the unpaired two-element shape does.
 enum { TEND_FUSED = 0, TEND_VOLUME = 1, TEND_FACES = 2 };
-template <class P, int NQ, int NQV>
+template <class P, int NQ, int NQV, bool PAIR = false>
 struct TendencyShape {
     using KD = KDims<NQ, NQV>;
-    static constexpr bool SPLIT = KD::Np > 125 && node_cache_size<P>::value == 0 && CMDG_TEND_SPLIT_LARGE != 0;
-    static constexpr int EPB = node_cache_size<P>::value != 0 || SPLIT
-                                   ? 1
-                                   : (KD::Np > 125 ? CMDG_TEND_EPB_LARGE : CMDG_TEND_EPB_SMALL);
-    static constexpr int NTE = EPB == 1 ? KD::NT : (KD::Np > KD::NFT ? KD::Np : KD::NFT);
+    static constexpr bool PAIRABLE = node_cache_size<P>::value == 0 && NQ == NQV;
+    static constexpr bool SPLIT = KD::Np > 125 && node_cache_size<P>::value == 0 && CMDG_TEND_SPLIT_LARGE != 0 && !PAIR;
+    static constexpr int EPB = PAIR ? 2
+                                    : (node_cache_size<P>::value != 0 || SPLIT
+                                           ? 1
+                                           : (KD::Np > 125 ? CMDG_TEND_EPB_LARGE : CMDG_TEND_EPB_SMALL));
+    static constexpr bool STAGE_M = EPB == 1 || (PAIR && KD::Np <= 125);
+    static constexpr int NTE = EPB == 1 || (PAIR && KD::Np <= 125) ? KD::NT : (KD::Np > KD::NFT ? KD::Np : KD::NFT);
     static constexpr int NT = EPB == 1 ? KD::NT : ((EPB * NTE + 63) / 64) * 64;
     static constexpr int NTV = ((KD::Np + 63) / 64) * 64;  // threads of the volume half
     static int64_t blocks(int64_t nelems) { return (nelems + EPB - 1) / EPB; }
@@ -385,45 +398,82 @@ struct TendencyShape {
 // handle whose exchanges are not unpacked).  A variant of its own: the second addressing mode
 // costs the Held-Suarez instantiation 24 VGPRs (128 -> 150, one wave per SIMD less), which the
 // interior launches and single-rank handles do not pay.
-template <class P, int NQ, int NQV, int MODE>
+template <class P, int NQ, int NQV, int MODE, bool PAIR = false>
 constexpr int tendency_threads()
 {
-    return MODE == TEND_VOLUME ? TendencyShape<P, NQ, NQV>::NTV : TendencyShape<P, NQ, NQV>::NT;
+    return MODE == TEND_VOLUME ? TendencyShape<P, NQ, NQV, PAIR>::NTV : TendencyShape<P, NQ, NQV, PAIR>::NT;
 }
-template <class P, int NQ, int NQV, bool LSRK, bool USE_GF, bool RECV = false, int MODE = TEND_FUSED>
-__global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, MODE>()),
-                                   (MODE == TEND_FUSED ? CMDG_TEND_MINW
-                                                       : (MODE == TEND_VOLUME ? CMDG_TENDV_MINW : CMDG_TENDF_MINW)))
-    k_tendency(const PassArgs<P> a)
+// doubles of LDS a paired fused launch takes (what tendency_body lays out; checked there)
+template <class P, int NQ, int NQV, bool USE_GF, bool PAIR>
+struct TendencyLds {
+    using KD = KDims<NQ, NQV>;
+    using SH = TendencyShape<P, NQ, NQV, PAIR>;
+    static constexpr int NPLANE = P::NFAUX + (USE_GF ? P::NGF : 0) + P::NHYP;
+    static constexpr int NMF = (SH::STAGE_M ? NPLANE : 0) + node_cache_size<P>::value;
+    static constexpr int doubles =
+        NQ * NQ + (NQV == NQ ? 0 : NQV * NQV) + SH::EPB * 3 * P::NS * KD::Np +
+        SH::EPB * (NMF > 0 ? NMF : 1) * (NMF > 0 ? SurfDims<NQ, NQV>::NSURF : 1) + SH::EPB * P::NS * KD::Np +
+        (PAIR && !SH::STAGE_M && NPLANE > 0 ? 2 * NPLANE * KD::Nfph : 1);
+};
+
+template <class P, int NQ, int NQV, bool LSRK, bool USE_GF, bool RECV = false, int MODE = TEND_FUSED,
+          bool PAIR = false, bool DYNLDS = false>
+__device__ __forceinline__ void tendency_body(const PassArgs<P> &a)
 {
     using KD = KDims<NQ, NQV>;
     const double a_t = a.tptr ? *a.tptr : a.t;  // (uniform: one scalar load)
-    using SH = TendencyShape<P, NQ, NQV>;
+    using SH = TendencyShape<P, NQ, NQV, PAIR>;
     constexpr int EPB = SH::EPB;
     constexpr bool VOL = MODE != TEND_FACES, FACES = MODE != TEND_VOLUME;
     static_assert(MODE == TEND_FUSED || (EPB == 1 && node_cache_size<P>::value == 0),
                   "the two-launch form takes one element per work-group and no node cache");
-    constexpr bool STAGE_M = EPB == 1;
+    static_assert(!PAIR || (MODE == TEND_FUSED && SH::PAIRABLE), "paired work-groups: fused form, one order, no node cache");
+    constexpr bool STAGE_M = SH::STAGE_M;
     constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGF = P::NGF,
                   NHYP = P::NHYP, NHG = 3 * P::NGL, NFA = P::NFAUX,
                   NSURF = SurfDims<NQ, NQV>::NSURF, NGFS = USE_GF ? NGF : 0,
                   NCA = node_cache_size<P>::value,
                   NMF = (STAGE_M && FACES ? NFA + NGFS + NHYP : 0) + NCA, OCA = NMF - NCA;
-    __shared__ double sD[VOL ? NQ * NQ + (NQV == NQ ? 0 : NQV * NQV) : 1];
+    // LDS: sD derivative matrices; sF_ contravariant flux [d][s][ijk], later the accumulator
+    // (interface half alone: the accumulator); sM_ minus side, surface nodes [field][sidx]; sQ_ the
+    // prognostic state of every node (minus side of the faces, and the "Q" of the fused update at the
+    // end: re-reading it from memory 20 us after the first read misses L2); sP_ (PAIR, minus side
+    // not staged) the face fields of the nodes of the shared face [elem][field][n].
+    // DYNLDS: the same arrays carved out of the launch's dynamic LDS -- the compiler then does not
+    // know the footprint and cannot relax a register budget on its account (k_tendency_pair_small).
+    constexpr int NPF = PAIR && !STAGE_M ? NFA + NGFS + NHYP : 0, NPL = KD::Nfph;
+    constexpr int LD = VOL ? NQ * NQ + (NQV == NQ ? 0 : NQV * NQV) : 1, LF = EPB * (VOL ? 3 : 1) * NS * Np,
+                  LM = EPB * (NMF > 0 ? NMF : 1) * (NMF > 0 ? NSURF : 1), LQ = FACES ? EPB * NS * Np : 1,
+                  LP = NPF > 0 ? 2 * NPF * NPL : 1;
+    static_assert(!DYNLDS || TendencyLds<P, NQ, NQV, USE_GF, PAIR>::doubles == LD + LF + LM + LQ + LP,
+                  "TendencyLds out of step with the kernel");
+    double *sD, *sF_, *sM_, *sQ_, *sP_;
+    if constexpr (DYNLDS) {
+        extern __shared__ double cmdg_dyn_lds[];
+        sD = cmdg_dyn_lds;
+        sF_ = sD + LD;
+        sM_ = sF_ + LF;
+        sQ_ = sM_ + LM;
+        sP_ = sQ_ + LQ;
+    } else {
+        __shared__ double aD[LD], aF[LF], aM[LM], aQ[LQ], aP[LP];
+        sD = aD, sF_ = aF, sM_ = aM, sQ_ = aQ, sP_ = aP;
+    }
     const double *const sDv = sD + (NQV == NQ ? 0 : NQ * NQ);  // vertical derivative matrix
-    // contravariant flux [d][s][ijk]; later the accumulator (interface half alone: the accumulator)
-    __shared__ double sF_[EPB * (VOL ? 3 : 1) * NS * Np];
-    // minus side, surface nodes [field][sidx]
-    __shared__ double sM_[EPB * (NMF > 0 ? NMF : 1) * (NMF > 0 ? NSURF : 1)];
-    // the prognostic state of every node: minus side of the faces, and the "Q" of the fused
-    // update at the end (re-reading it from memory 20 us after the first read misses L2)
-    __shared__ double sQ_[FACES ? EPB * NS * Np : 1];
     // this thread's element of the work-group and its index there
     const int sub = EPB == 1 ? 0 : (int)threadIdx.x / SH::NTE;
     const int tid = EPB == 1 ? (int)threadIdx.x : (int)threadIdx.x - sub * SH::NTE;
     const int64_t li = (int64_t)EPB * xcd_remap(blockIdx.x, gridDim.x) + sub;
-    const bool live = EPB == 1 || (sub < EPB && li < a.nelems);
-    const int64_t e = live ? a.elems[li] - 1 : 0;
+    // PAIR: entry (e0, e1) of the pair list; e1 > 0: the two share e0's xi1+ face
+    int64_t raw = 0;
+    bool paired = false;
+    if constexpr (PAIR) {
+        const int64_t r1 = a.elems[li - sub + 1];
+        paired = r1 > 0;
+        raw = sub == 0 ? a.elems[li - sub] : (sub == 1 ? (r1 < 0 ? -r1 : r1) : 0);
+    }
+    const bool live = PAIR ? raw != 0 : (EPB == 1 || (sub < EPB && li < a.nelems));
+    const int64_t e = live ? (PAIR ? raw : a.elems[li]) - 1 : 0;
     const int lsub = live ? sub : 0;
     double *const sF = sF_ + lsub * ((VOL ? 3 : 1) * NS * Np);
     double *const sM = sM_ + lsub * ((NMF > 0 ? NMF : 1) * (NMF > 0 ? NSURF : 1));
@@ -447,7 +497,8 @@ __global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, MODE>()),
         int f_f = 0, f_n = 0;
         KD::face_task(tid, f_f, f_n);
         face_on = live && tid < KD::NFT && (f_f < 4 ? hz : vt);
-        if (face_on) face_index<NQ, NQV>(a.g, e, tid, f_f, f_idP, f_bctag);
+        // (the shared face of a pair has no table entry to load: interior, plus side in LDS)
+        if (face_on && !(PAIR && paired && f_f == 1 - lsub)) face_index<NQ, NQV>(a.g, e, tid, f_f, f_idP, f_bctag);
     }
     Vec<NS> S;
     double MI = 0;
@@ -497,6 +548,19 @@ __global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, MODE>()),
         if constexpr (FACES) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) sQ[s * Np + tid] = lQ[s];
+        }
+        if constexpr (NPF > 0) {  // the shared face's fields, for the partner's plus side
+            if (paired && tid % NQ == (lsub == 0 ? NQ - 1 : 0)) {
+                double *sP = sP_ + lsub * (NPF * NPL) + tid / NQ;
+#pragma unroll
+                for (int s = 0; s < NFA; ++s) sP[s * NPL] = laux[P::face_aux(s)];
+                if (use_gf) {
+#pragma unroll
+                    for (int s = 0; s < NGF; ++s) sP[(NFA + s) * NPL] = lgf[s];
+                }
+#pragma unroll
+                for (int s = 0; s < NHYP; ++s) sP[(NFA + NGFS + s) * NPL] = lhyp[s];
+            }
         }
         if (FACES && STAGE_M && sidx >= 0) {  // stage the minus side of the interface phase
 #pragma unroll
@@ -643,7 +707,9 @@ __global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, MODE>()),
                             : a.aux[fp.vidM + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * e)];
 #pragma unroll
             for (int s = 0; s < NGF; ++s) gfM[s] = gfP[s] = 0.0;
-            const int gslot = RECV ? ghost_slot<Np>(a.h, fp.eP, fp.vidP) : -1;
+            // PAIR: the face this element shares with its partner in the work-group
+            const bool shared_face = PAIR && paired && f == 1 - lsub;
+            const int gslot = RECV && !shared_face ? ghost_slot<Np>(a.h, fp.eP, fp.vidP) : -1;
             if (use_gf) {
                 if constexpr (STAGE_M) {
 #pragma unroll
@@ -651,20 +717,49 @@ __global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, MODE>()),
                 } else {
                     load_state<NGF, Np>(gfM, a.gf, fp.vidM, e);
                 }
-                load_plus<NGF, Np, NGF>(gfP, a.gf, a.h.recvGF, gslot, fp.vidP, fp.eP);
             }
 #pragma unroll
             for (int s = 0; s < NHYP; ++s)
                 hypM[s] = STAGE_M ? sM[(NFA + NGFS + s) * NSURF + sidx]
                                   : a.hypgrad[fp.vidM + (int64_t)Np * (s + (int64_t)NHG * e)];
-            load_plus<NS, Np, NS>(QPn, a.Q, a.h.recvQ, gslot, fp.vidP, fp.eP);
 #pragma unroll
             for (int s = 0; s < NAUX; ++s) auxPn[s] = 0;
+            if (shared_face) {  // plus side = the partner's staged minus side at the same face node
+                const int psub = 1 - lsub, vidP = face_vid<NQ, NQV>(f ^ 1, n);
+                const double *sQp = sQ_ + psub * (NS * Np);
 #pragma unroll
-            for (int s = 0; s < NFA; ++s)
-                auxPn[P::face_aux(s)] =
-                    a.aux[fp.vidP + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * fp.eP)];
-            load_plus<NHG, Np, NHYP>(hypP, a.hypgrad, a.h.recvHG, gslot, fp.vidP, fp.eP);
+                for (int s = 0; s < NS; ++s) QPn[s] = sQp[s * Np + vidP];
+                if constexpr (STAGE_M) {
+                    const double *sMp = sM_ + psub * ((NMF > 0 ? NMF : 1) * (NMF > 0 ? NSURF : 1));
+                    const int sidxP = surf_index<NQ, NQV>(vidP);
+#pragma unroll
+                    for (int s = 0; s < NFA; ++s) auxPn[P::face_aux(s)] = sMp[s * NSURF + sidxP];
+                    if (use_gf) {
+#pragma unroll
+                        for (int s = 0; s < NGF; ++s) gfP[s] = sMp[(NFA + s) * NSURF + sidxP];
+                    }
+#pragma unroll
+                    for (int s = 0; s < NHYP; ++s) hypP[s] = sMp[(NFA + NGFS + s) * NSURF + sidxP];
+                } else if constexpr (NPF > 0) {
+                    const double *sPp = sP_ + psub * (NPF * NPL) + n;
+#pragma unroll
+                    for (int s = 0; s < NFA; ++s) auxPn[P::face_aux(s)] = sPp[s * NPL];
+                    if (use_gf) {
+#pragma unroll
+                        for (int s = 0; s < NGF; ++s) gfP[s] = sPp[(NFA + s) * NPL];
+                    }
+#pragma unroll
+                    for (int s = 0; s < NHYP; ++s) hypP[s] = sPp[(NFA + NGFS + s) * NPL];
+                }
+            } else {
+                if (use_gf) load_plus<NGF, Np, NGF>(gfP, a.gf, a.h.recvGF, gslot, fp.vidP, fp.eP);
+                load_plus<NS, Np, NS>(QPn, a.Q, a.h.recvQ, gslot, fp.vidP, fp.eP);
+#pragma unroll
+                for (int s = 0; s < NFA; ++s)
+                    auxPn[P::face_aux(s)] =
+                        a.aux[fp.vidP + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * fp.eP)];
+                load_plus<NHG, Np, NHYP>(hypP, a.hypgrad, a.h.recvHG, gslot, fp.vidP, fp.eP);
+            }
 #pragma unroll
             for (int s = 0; s < NS; ++s) QPd[s] = QPn[s];
 #pragma unroll
@@ -751,6 +846,29 @@ __global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, MODE>()),
                 return sQ[s * Np + n] + a.rkb_dt * sT[s * Np + n];
             });
     }
+}
+
+template <class P, int NQ, int NQV, bool LSRK, bool USE_GF, bool RECV = false, int MODE = TEND_FUSED,
+          bool PAIR = false>
+__global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, MODE, PAIR>()),
+                                   (MODE == TEND_FUSED ? CMDG_TEND_MINW
+                                                       : (MODE == TEND_VOLUME ? CMDG_TENDV_MINW : CMDG_TENDF_MINW)))
+    k_tendency(const PassArgs<P> a)
+{
+    tendency_body<P, NQ, NQV, LSRK, USE_GF, RECV, MODE, PAIR>(a);
+}
+// Paired work-groups of small elements: 384 threads are six waves, which a CU places 2-1-2-1 over its
+// SIMDs, so a second work-group is resident only at <= 128 VGPRs (profiles/r02_lds_occupancy.jsonl;
+// unconstrained the Held-Suarez instantiation takes 154 and runs at half the occupancy, twice the
+// time: profiles/r04_ab_tendency_pairs.txt).  Neither a waves-per-SIMD request nor amdgpu_num_vgpr
+// gets there with static LDS -- the compiler relaxes both to what 62 KB of LDS per work-group
+// allow, three waves per SIMD ("failed to meet occupancy target") -- so this kernel takes its LDS
+// dynamically: the footprint is then unknown at compile time and four waves per SIMD are honoured.
+template <class P, int NQ, int NQV, bool LSRK, bool USE_GF, bool RECV>
+__global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, TEND_FUSED, true>()), 4)
+    k_tendency_pair_small(const PassArgs<P> a)
+{
+    tendency_body<P, NQ, NQV, LSRK, USE_GF, RECV, TEND_FUSED, true, true>(a);
 }
 
 // ---------------------------------------------------------------------------------

@@ -28,7 +28,7 @@ int order(EngineBase *e, hipStream_t earlier, hipStream_t later)
 {
     if (earlier == later) return CMDG_OK;
     if (dbg_sync() & 1) (void)hipStreamSynchronize(earlier);
-    if (hipEventRecord(e->ev_comp, earlier) != hipSuccess ||
+    if (ev_record(e->ev_comp, earlier) != hipSuccess ||
         hipStreamWaitEvent(later, e->ev_comp, 0) != hipSuccess)
         return e->fail(CMDG_ERR_HIP, "split explicit: stream ordering failed");
     return CMDG_OK;

@@ -22,7 +22,7 @@ unsigned nblocks01(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 2
 int order01(EngineBase *e, hipStream_t earlier, hipStream_t later)
 {
     if (earlier == later) return CMDG_OK;
-    if (hipEventRecord(e->ev_comp, earlier) != hipSuccess ||
+    if (ev_record(e->ev_comp, earlier) != hipSuccess ||
         hipStreamWaitEvent(later, e->ev_comp, 0) != hipSuccess)
         return e->fail(CMDG_ERR_HIP, "split explicit 01: stream ordering failed");
     return CMDG_OK;

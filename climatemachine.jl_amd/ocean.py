@@ -276,11 +276,17 @@ class SplitExplicitSolver:
     place by ``nsteps`` slow steps; the coupling runs when the slow law is ``Coupled``."""
 
     def __init__(self, dg_slow, dg_fast, Q_slow, Q_fast, dt_slow, dt_fast, t0=0.0,
-                 coefficients=None):
+                 coefficients=None, fast_priority=None):
         from . import _lib
         from .odesolvers import LSRK54CarpenterKennedy
         import ctypes as C
+        import os
         self.dg_slow, self.dg_fast = dg_slow, dg_fast
+        # the barotropic sub-steps are a chain of small launches whose length decides the length of
+        # a slow stage: their streams go first (CMDG_OPT_STREAM_PRIORITY; results do not depend on it)
+        if fast_priority is None:
+            fast_priority = os.environ.get("CMDG_OCEAN_FAST_PRIORITY", "1") != "0"
+        dg_fast.set_option(_lib.OPT_STREAM_PRIORITY, int(bool(fast_priority)))
         self.dt, self.dt_fast, self.t, self.steps = float(dt_slow), float(dt_fast), float(t0), 0
         if coefficients is None:
             ref = LSRK54CarpenterKennedy(dg_fast, Q_fast)

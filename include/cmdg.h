@@ -197,12 +197,32 @@ int cmdg_synchronize(cmdg_handle h);
  * CMDG_OPT_STEP_GRAPH (default 0; environment CMDG_STEP_GRAPH=1): cmdg_lsrk_run records one step
  *   into a HIP graph and replays it for every step but the first of a run; the evaluation times
  *   live in device memory and advance as updatetime! does.  Results are bit-identical.
- *   Single-rank handles only: handles that exchange stay eager (RCCL operations inside a stream
- *   capture crash hipStreamEndCapture with RCCL 2.26.6 / ROCm 7.0.2), and so do runs a capture
- *   cannot hold (profiling, filters, hooks, a nodal update_auxiliary_state! kernel of its own). */
+ *   Handles that exchange through RCCL are recorded too when their exchanges run direct and
+ *   pipelined (CMDG_Q_HALO_PIPELINE): one hipGraphLaunch then stands for the 40 kernel launches,
+ *   100 event operations and 20 RCCL groups of a Held-Suarez step.  What crashed in round 3 is
+ *   settled (scripts/probe/rccl_capture_probe.py, one fresh process per hypothesis, both stacks):
+ *   on HIP 7.0.2 / RCCL 2.26.6 hipStreamEndCapture segfaults if and only if an ncclSend / ncclRecv
+ *   group was recorded on a stream that JOINED the capture through an event -- Global or Relaxed
+ *   mode alike; on the origin stream every mode, several operations per group and several groups
+ *   per capture are fine; ROCm 7.2 / RCCL 2.27.7 accepts both forms (the probes use a rank as its
+ *   own peer: whether the crash needs the self-send cannot be told on one GPU, and does not matter
+ *   for the remedy).  The
+ *   library therefore begins such a capture on the halo stream (the groups' stream) and forks the
+ *   compute stream.  Runs a capture cannot hold stay eager: profiling, filters, hooks, a nodal
+ *   update_auxiliary_state! kernel of its own, the local transport, exchanges that are packed.
+ * CMDG_OPT_TENDENCY_PAIRS (default 0; environment CMDG_TENDENCY_PAIRS=1): the tendency pass takes
+ *   horizontally adjacent elements two to a work-group and reads the xi1 face they share out of
+ *   LDS instead of gathering it (laws with one polynomial order and no node cache; the pairs are
+ *   found from vmap+ at create: faces that meet node for node).  Results are bit-identical.
+ * CMDG_OPT_STREAM_PRIORITY (default 0): 1 puts both streams of the handle at the device's highest
+ *   stream priority.  Meant for a handle whose launches are small and form a long dependent chain
+ *   next to another handle's bandwidth-bound launches (the barotropic model of the split-explicit
+ *   ocean, whose sub-steps decide the length of a slow stage).  The handle must be idle; results
+ *   do not depend on it. */
 enum {
     CMDG_OPT_KEEP_GRADFLUX = 1, CMDG_OPT_STACK_HEIGHT = 2, CMDG_OPT_REFERENCE_HALO = 3,
-    CMDG_OPT_HALO_PIPELINE = 4, CMDG_OPT_STEP_GRAPH = 5
+    CMDG_OPT_HALO_PIPELINE = 4, CMDG_OPT_STEP_GRAPH = 5, CMDG_OPT_STREAM_PRIORITY = 6,
+    CMDG_OPT_TENDENCY_PAIRS = 7
 };
 int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value);
 
@@ -225,6 +245,7 @@ enum {
     CMDG_Q_HOST_POST_NS = 10,   /* host nanoseconds spent posting exchanges (RCCL group calls) ... */
     CMDG_Q_HOST_POST_COUNT = 11, /* ... and how many were posted, since the handle was created */
     CMDG_Q_GRAPH_STEPS = 12,     /* steps cmdg_lsrk_run replayed from a captured graph */
+    CMDG_Q_TENDENCY_PAIRS = 13,  /* work-groups of the tendency pass that share a face (-1: option off) */
     CMDG_Q_STATE_READ = 16, CMDG_Q_AUX_READ = 20
 };
 int cmdg_query(cmdg_handle h, int32_t what, int64_t *out);
@@ -403,7 +424,9 @@ typedef struct cmdg_rhs_hooks {
      *   operations above run here instead of after the gradient pass; then the flow deviation.
      * Single rank only (the nested operator would need its own ghost exchange).
      * Lifetime: the nested handle may be destroyed first -- cmdg_destroy detaches it from every
-     * handle whose hooks name it (their hooks then run without the nested operator). */
+     * handle whose hooks name it; such a handle then fails every evaluation with CMDG_ERR_INVALID
+     * ("the nested operator of this handle was destroyed") until cmdg_set_rhs_hooks gives it new
+     * hooks (or NULL): it never goes on computing a different law. */
     int32_t ops_before_gradients;
     cmdg_handle pre_rhs_handle;
     int32_t pre_rhs_src_col, pre_rhs_dst_aux_col;

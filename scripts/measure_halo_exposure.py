@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--nhorz", type=int, default=0)
     ap.add_argument("--reference-halo", action="store_true",
                     help="pack / unpack kernels around every exchange (CMDG_OPT_REFERENCE_HALO)")
+    ap.add_argument("--step-graph", action="store_true",
+                    help="record one step into a HIP graph and replay it (CMDG_OPT_STEP_GRAPH)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="interior and exterior launches on one stream (CMDG_OPT_HALO_PIPELINE = 0)")
     args = ap.parse_args()
@@ -65,6 +67,8 @@ def main():
         dg.set_option(cm._lib.OPT_REFERENCE_HALO, 1)
     if args.no_pipeline:
         dg.set_option(cm._lib.OPT_HALO_PIPELINE, 0)
+    if args.step_graph:
+        dg.set_option(cm._lib.OPT_STEP_GRAPH, 1)
     modes = {k: dg.query(k) for k in ("DIRECT_SEND", "DIRECT_RECV", "HALO_PIPELINE")}
     Q = dg.init_ode_state(0.0)
     solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
@@ -82,6 +86,7 @@ def main():
         runs.append(time.perf_counter() - t0)
     el = min(runs)
     h1 = (dg.query("HOST_POST_NS"), dg.query("HOST_POST_COUNT"))
+    graph_steps = dg.query("GRAPH_STEPS")
     Q.copy_(dg.init_ode_state(0.0))
     torch.cuda.synchronize()
     dg.profile_reset()
@@ -98,6 +103,7 @@ def main():
            "ms_per_step": 1e3 * el / args.steps, "steps": args.steps,
            "ms_per_step_runs": [1e3 * r / args.steps for r in runs],
            "host_enqueue_ms_per_step": 1e3 * min(enq) / args.steps,
+           "step_graph": bool(args.step_graph), "graph_steps_replayed": int(graph_steps),
            "host_rccl_post_us_per_exchange": 1e-3 * (h1[0] - h0[0]) / max(h1[1] - h0[1], 1), "kernels": {}}
     for k in ("GRADIENTS", "GRADIENTS_EXT", "DIVGRAD", "DIVGRAD_EXT", "GRADLAP", "GRADLAP_EXT", "TENDENCY",
               "TENDENCY_EXT", "PACK", "TRANSPORT", "UNPACK", "HALO_EXPOSED"):
@@ -109,6 +115,23 @@ def main():
         out["exposed_ms_per_step"] = ex["total_ms_per_step"]
         out["exposed_fraction_of_step"] = ex["total_ms_per_step"] / out["ms_per_step"]
         out["exchanges_per_stage"] = ex["launches"] / (5 * args.steps)
+    if args.step_graph:   # the same 100 steps from the same state and time, replayed and eager: same bits?
+        res = []
+        for graph in (1, 0):
+            dg.set_option(cm._lib.OPT_STEP_GRAPH, graph)
+            Q.copy_(dg.init_ode_state(0.0))
+            torch.cuda.synchronize()
+            solver.t = 0.0
+            g0 = dg.query("GRAPH_STEPS")
+            # (few steps: with every neighbour mapped to the rank itself the flow is not physical
+            # and does not stay finite for long)
+            solver.dostep(Q, nsteps=min(args.steps, 3))
+            dg.synchronize()
+            res.append((Q[:grid.nreal].cpu().numpy().copy(), dg.query("GRAPH_STEPS") - g0))
+        # (bit equality, NaN positions included: the rehearsal's flow need not stay finite)
+        out["graph_equals_eager"] = bool(np.array_equal(res[0][0], res[1][0], equal_nan=True))
+        out["graph_check_nonfinite_values"] = int((~np.isfinite(res[0][0])).sum())
+        out["graph_check_steps_replayed"] = [int(res[0][1]), int(res[1][1])]
     print(json.dumps(out))
     dg.close()
 

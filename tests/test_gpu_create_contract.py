@@ -49,8 +49,9 @@ def test_create_accepts_the_unmodified_grid_and_reports_no_neighbours(cm, torch)
 
 def test_nested_handle_may_be_destroyed_first(cm, torch):
     """``hooks.pre_rhs_handle``: destroying the nested Continuity3d operator before its parent
-    detaches it (include/cmdg.h); the parent then evaluates without it instead of reading freed
-    memory.  (OceanDGModel01.close() still releases them in the safe order.)"""
+    detaches it (include/cmdg.h); the parent then refuses to evaluate -- it would compute another
+    law than the one it was given -- instead of reading freed memory or going on silently, until
+    new hooks are set.  (OceanDGModel01.close() still releases them in the safe order.)"""
     from helpers import simple_box_2dt_setup
     model, g3, _, _ = simple_box_2dt_setup(Nx=3, Ny=3, Nz=3)
     odg = cm.ocean01.OceanDGModel01(model, g3)
@@ -59,9 +60,11 @@ def test_nested_handle_may_be_destroyed_first(cm, torch):
     torch.cuda.synchronize()
     odg.dg(T1, Q, 0.0, 1.0, 0.0)
     odg.conti3d_dg.close()                      # the child goes first
-    odg.dg(T2, Q, 0.0, 1.0, 0.0)                # no use after free: runs, without the nested operator
-    assert torch.isfinite(T2[:g3.nreal]).all()
+    with pytest.raises(RuntimeError, match="nested operator of this handle was destroyed"):
+        odg.dg(T2, Q, 0.0, 1.0, 0.0)            # no use after free, and no other physics either
     odg.dg.set_rhs_hooks()
+    odg.dg(T2, Q, 0.0, 1.0, 0.0)                # without hooks: the plain operator again
+    assert torch.isfinite(T2[:g3.nreal]).all()
     for f in (odg.fu, odg.ft):
         f.close()
     odg.dg.close()

@@ -226,9 +226,8 @@ def test_step_graph_equals_eager_steps(cm, torch):
     """CMDG_OPT_STEP_GRAPH: cmdg_lsrk_run replays one captured step (stage times from device
     memory, advanced as updatetime! does) for every step but the first of a run.  Same bits as
     eager steps; two runs reuse the graph; the time really advances (the advection-diffusion
-    law's boundary data depend on it).  A handle that exchanges stays eager: RCCL operations
-    inside a stream capture crash hipStreamEndCapture on this stack (csrc/cmdg.hip,
-    graph_eligible)."""
+    law's boundary data depend on it).  A handle that exchanges through RCCL is recorded with the
+    halo stream as the origin of the capture (csrc/cmdg.hip, graph_eligible): same bits again."""
     from helpers import pseudo1d_setup
     from test_gpu_halo import _self_neighbour_grid
     out, counts = [], []
@@ -247,14 +246,52 @@ def test_step_graph_equals_eager_steps(cm, torch):
     assert counts == [0, 3 + 2], counts
     assert np.isfinite(out[0]).all() and np.abs(out[0]).max() > 0
     assert np.array_equal(out[0], out[1])
-    # with neighbours the option changes nothing
-    grid = _self_neighbour_grid(cm, 0, 2)
-    grid.nabrtorank = [0] * len(grid.nabrtorank)
-    dg = cm.dgmodel.DGModel(pseudo1d_setup()[0], grid, direction=0)
-    dg.comm_init_rccl(cm.dgmodel.rccl_unique_id(), 0, 1)
-    dg.set_option(cm._lib.OPT_STEP_GRAPH, 1)
-    Q = dg.init_ode_state(0.0)
-    cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=1e-4).dostep(Q, nsteps=3)
-    dg.synchronize()
-    assert dg.query("GRAPH_STEPS") == 0 and torch.isfinite(Q[:grid.nreal]).all()
-    dg.close()
+    # with neighbours (RCCL, the rank as its own neighbour): the groups are recorded as well
+    out, counts = [], []
+    for graph in (0, 1):
+        grid = _self_neighbour_grid(cm, 0, 2)
+        grid.nabrtorank = [0] * len(grid.nabrtorank)
+        dg = cm.dgmodel.DGModel(pseudo1d_setup()[0], grid, direction=0)
+        dg.comm_init_rccl(cm.dgmodel.rccl_unique_id(), 0, 1)
+        dg.set_option(cm._lib.OPT_STEP_GRAPH, graph)
+        assert dg.query("HALO_PIPELINE") == 1
+        Q = dg.init_ode_state(0.0)
+        solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=1e-4)
+        solver.dostep(Q, nsteps=4)
+        solver.dostep(Q, nsteps=3)
+        dg.synchronize()
+        counts.append(dg.query("GRAPH_STEPS"))
+        out.append(Q[:grid.nreal].cpu().numpy().copy())
+        dg.close()
+    assert counts == [0, 3 + 2], counts
+    assert np.isfinite(out[0]).all() and np.abs(out[0]).max() > 0
+    assert np.array_equal(out[0], out[1])
+
+
+def test_step_graph_is_recorded_again_after_an_option_changes_the_launches(cm, torch):
+    """A recorded step holds the kernels of the options it was recorded under.  Held-Suarez has no
+    viscosity, so by default ``state_gradient_flux`` is not formed; CMDG_OPT_KEEP_GRADFLUX switches
+    to the kernels that refresh it.  Setting it between two graph runs must drop the graph: the
+    second run's gradient flux equals the eager handle's, bit for bit (a stale graph would leave
+    it untouched)."""
+    from helpers import held_suarez_setup
+    res = []
+    for graph in (0, 1):
+        law, grid, direction, diffusion_direction = held_suarez_setup()
+        dg = cm.dgmodel.DGModel(law, grid, direction=direction, diffusion_direction=diffusion_direction)
+        dg.set_option(cm._lib.OPT_STEP_GRAPH, graph)
+        Q = dg.init_ode_state(0.0)
+        solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=1.0)
+        solver.dostep(Q, nsteps=3)
+        dg.synchronize()
+        assert float(dg.state_gradient_flux.abs().max()) == 0.0     # not formed
+        n0 = dg.query("GRAPH_STEPS")
+        dg.set_option(cm._lib.OPT_KEEP_GRADFLUX, 1)
+        solver.dostep(Q, nsteps=3)
+        dg.synchronize()
+        res.append((Q[:grid.nreal].cpu().numpy().copy(),
+                    dg.state_gradient_flux[:grid.nreal].cpu().numpy().copy(), n0, dg.query("GRAPH_STEPS")))
+        dg.close()
+    (Qe, ge, _, ne), (Qg, gg, n0, n1) = res
+    assert ne == 0 and n0 == 2 and n1 == 4
+    assert np.abs(ge).max() > 0 and np.array_equal(ge, gg) and np.array_equal(Qe, Qg)

@@ -176,12 +176,16 @@ def test_shallow_water_alone_reproduces_reference_table(cm, oracle, torch, N_ext
     dg.close()
 
 
+@pytest.mark.parametrize("priority", [0, 1])
 @pytest.mark.parametrize("size", [2, 3])
-def test_partitioned_split_explicit_matches_single_rank(cm, torch, size):
+def test_partitioned_split_explicit_matches_single_rank(cm, torch, size, priority, monkeypatch):
     """The coupled stepper on a column partition (per-rank slow / fast pairs connected through
     the local transport, driven by cmdg_group_split_explicit_step) against the one-rank run:
     the flow deviation of ghost stacks is integrated from the received face pencils, so the
-    result does not depend on the partition."""
+    result does not depend on the partition -- nor on the halo streams' priority (round 3's
+    failure with CMDG_HALO_PRIORITY=1 was a fill of the lazily allocated LSRK work states that
+    was not ordered before the first stage; test_priority_halo_streams_first_use_in_a_process)."""
+    monkeypatch.setenv("CMDG_HALO_PRIORITY", str(priority))
     O = cm.ocean
     central = cm.balancelaws.CentralNumericalFluxFirstOrder
     law3, g3, law2, g2 = split_explicit_setup(True, Nx=4, Ny=3, Nz=3)
@@ -243,6 +247,23 @@ def test_partitioned_split_explicit_matches_single_rank(cm, torch, size):
         d3.close()
     for d2 in fasts + [dg2]:
         d2.close()
+
+
+def test_priority_halo_streams_first_use_in_a_process():
+    """Round 3's ordering failure showed only on the FIRST partitioned step of a process (later
+    handles found the freed work states' pages still holding valid numbers): a fresh process with
+    high-priority halo streams, three handle generations, each equal to the one-rank run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CMDG_HALO_PRIORITY="1")
+    env.pop("CMDG_DBG_WORK_MEMSET", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "probe", "priority_order_diag.py")],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("trial") and "worst" in l]
+    assert len(lines) == 3 and all(l.endswith("OK") for l in lines), r.stdout[-2000:]
 
 
 def test_rotating_box_split_explicit_meets_the_reference_bound(cm, oracle, torch):
