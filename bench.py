@@ -23,6 +23,9 @@ import time
 # before either; nothing on the GPU path depends on them.
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
+# (with a binding policy libgomp pins the initial thread to the first place as soon as it is
+# loaded: the hardware threads this process may use are read now, not later)
+_AFFINITY_AT_START = len(os.sched_getaffinity(0))
 
 import numpy as np
 
@@ -259,7 +262,7 @@ def host_cpu_info():
     """What this process may use of the host: hardware threads in its affinity mask, the cgroup
     CPU quota (a container may see 128 threads and be allowed 16 CPUs' worth of time), sockets
     and physical cores behind the mask."""
-    info = {"affinity_threads": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": None,
+    info = {"affinity_threads": _AFFINITY_AT_START, "cgroup_cpu_quota": None,
             "sockets": None, "physical_cores": None}
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -277,7 +280,7 @@ def host_cpu_info():
         cores, cpu = set(), {}
         for line in open("/proc/cpuinfo"):
             if ":" not in line:
-                if "processor" in cpu and int(cpu["processor"]) in os.sched_getaffinity(0):
+                if "processor" in cpu:
                     cores.add((cpu.get("physical id", "0"), cpu.get("core id", cpu["processor"])))
                 cpu = {}
                 continue

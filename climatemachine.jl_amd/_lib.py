@@ -140,6 +140,8 @@ SYMBOLS = [
     ("cmdg_ocean_reconcile_from_fast_to_slow", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("cmdg_split_explicit01_step", C.c_int,
      [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i32, _vp, _vp, _vp]),
+    ("cmdg_group_split_explicit01_step", C.c_int,
+     [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i32, _vp, _vp, _vp]),
     ("cmdg_lsrk_update", C.c_int, [_vp, _vp, _vp, _d, _d]),
     ("cmdg_ls3n_step", C.c_int, [_vp, _vp, _vp, _vp, _d, _d, _i32, _vp, _vp, _vp]),
     ("cmdg_ssprk_step", C.c_int, [_vp, _vp, _vp, _vp, _d, _d, _i32, _vp, _vp, _vp]),

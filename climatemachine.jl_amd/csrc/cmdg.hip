@@ -636,11 +636,11 @@ int EngineBase::set_stream_priority(int level)
 {
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    if (level != 0 && level != 1) return fail(CMDG_ERR_INVALID, "stream priority: 0 (default) or 1 (highest)");
+    if (level < -1 || level > 1) return fail(CMDG_ERR_INVALID, "stream priority: 0 (default), 1 (highest) or -1 (lowest)");
     if (int r = synchronize()) return r;
     drop_graph();
     hipStream_t nc = nullptr, nm = nullptr;
-    const int prio = level ? hi : 0;
+    const int prio = level > 0 ? hi : (level < 0 ? lo : 0);
     HIPCHK(hipStreamCreateWithPriority(&nc, hipStreamNonBlocking, prio));
     HIPCHK(hipStreamCreateWithPriority(&nm, hipStreamNonBlocking, prio));
     hipStreamDestroy(s_comp);
@@ -854,7 +854,7 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
     switch (seg) {
     case 0:
         if (has_hooks) {
-            TRY(run_pre_hooks(c));  // update_auxiliary_state!(realelems) of the law
+            if (!c.pre_done) TRY(run_pre_hooks(c));  // update_auxiliary_state!(realelems) of the law
             slot[SLOT_Q].fresh_for = nullptr;  // (its filters rewrite Q)
         }
         if (!(grad && fused_update_aux())) launch_update_aux(c, 0, nreal);
@@ -873,6 +873,10 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
             // update_auxiliary_state!(ghostelems): the flow deviation of the ghost stacks
             if (has_hooks && hooks.has_flow_deviation)
                 TRY(flow_deviation(c.Qin, nreal / hooks.nvertelem, nghost / hooks.nvertelem));
+            // ... and, for a law that integrates in update_auxiliary_state! itself (SplitExplicit01's
+            // OceanModel), the column operators over the received face pencils of the ghost stacks:
+            // the kinematic pressure the rank-boundary faces read on their plus side
+            if (has_hooks && hooks.ops_before_gradients) TRY(run_column_ops(c, nreal, nelem));
         }
         if (dsend && gfl) TRY(before_direct_send(SLOT_GF, s_ext));
         if (dsend && hyper) TRY(before_direct_send(SLOT_HG, s_ext));
@@ -1009,7 +1013,31 @@ int group_rhs(std::vector<EngineBase *> &g, std::vector<RhsCtx> &c, bool keep_fr
 {
     if (!keep_fresh)
         for (auto *e : g) e->invalidate_sends();
+    for (auto &x : c) x.pre_done = false;
     if (dbg_sync() & 256) (void)hipDeviceSynchronize();
+    // handles whose update_auxiliary_state! evaluates a nested operator: the nested operators of
+    // the group exchange among themselves, so they run in lock step too, between the two halves
+    // of the composition (a single handle does the same inside segment 0, run_pre_hooks)
+    bool nested = false;
+    for (auto *e : g) nested = nested || (e->has_hooks && e->hooks.pre_rhs_handle);
+    if (nested && g.size() > 1) {
+        std::vector<EngineBase *> ch;
+        std::vector<RhsCtx> cc(g.size());
+        for (size_t i = 0; i < g.size(); ++i) {
+            if (!(g[i]->has_hooks && g[i]->hooks.pre_rhs_handle))
+                return g[i]->fail(CMDG_ERR_INVALID, "local group: every rank needs the nested operator");
+            if (int r = g[i]->run_pre_hooks_a(c[i], cc[i])) return r;
+            ch.push_back(g[i]->hooks.pre_rhs_handle->eng);
+        }
+        if (int r = group_rhs(ch, cc)) {
+            g[0]->err = "nested operator: " + ch[0]->err;
+            return r;
+        }
+        for (size_t i = 0; i < g.size(); ++i) {
+            if (int r = g[i]->run_pre_hooks_b(c[i])) return r;
+            c[i].pre_done = true;
+        }
+    }
     for (int s = 0; s < EngineBase::NSEG; ++s)
         for (size_t i = 0; i < g.size(); ++i)
             if (int r = g[i]->rhs_segment(s, c[i])) {
@@ -1357,8 +1385,8 @@ int EngineBase::set_hooks(const cmdg_rhs_hooks *hk)
         EngineBase *ch = hk->pre_rhs_handle->eng;
         if (!ch || ch == this || ch->Np != Np || ch->nelem != nelem || ch->ns != ns || ch->dev != dev)
             return fail(CMDG_ERR_INVALID, "hooks: the nested operator must share grid, state and device");
-        if (communicate() || ch->communicate())
-            return fail(CMDG_ERR_UNSUPPORTED, "hooks: a nested operator is single-rank only");
+        if (ch->nabrtorank != nabrtorank || ch->nreal != nreal)
+            return fail(CMDG_ERR_INVALID, "hooks: the nested operator must live on the same partition (same neighbours)");
         if (hk->pre_rhs_src_col < 0 || hk->pre_rhs_src_col >= ch->ns || hk->pre_rhs_dst_aux_col < 0 ||
             hk->pre_rhs_dst_aux_col >= naux)
             return fail(CMDG_ERR_INVALID, "hooks: nested operator column out of range");
@@ -1378,7 +1406,13 @@ int EngineBase::set_hooks(const cmdg_rhs_hooks *hk)
     return CMDG_OK;
 }
 
-int EngineBase::run_pre_hooks(const RhsCtx &c)
+// update_auxiliary_state!(dg, law, Q, t, realelems) as the recorded composition.  First half: the
+// pre filters, and the context of the nested operator's evaluation (whose stream is made to follow
+// this one); second half: its tendency column into the auxiliary state, the column operators, the
+// flow deviation.  Between the two the nested operator is evaluated -- by run_pre_hooks itself for
+// a single handle (one rank, or one RCCL rank per process: the nested operator exchanges with its
+// own communicator, in the same order on every rank), by group_rhs in lock step for a local group.
+int EngineBase::run_pre_hooks_a(const RhsCtx &c, RhsCtx &cc)
 {
     if (hooks_orphaned)
         return fail(CMDG_ERR_INVALID, "hooks: the nested operator of this handle was destroyed; set new hooks");
@@ -1390,13 +1424,20 @@ int EngineBase::run_pre_hooks(const RhsCtx &c)
         EngineBase *ch = hooks.pre_rhs_handle->eng;
         HIPCHK(ev_record(ev_comp, s_comp));
         HIPCHK(hipStreamWaitEvent(ch->s_comp, ev_comp, 0));
-        RhsCtx cc;
+        cc = RhsCtx();
         cc.tendency = d_preT;
         cc.Qin = c.Qin;
         cc.t = c.t;
         cc.alpha = 1.0;
         cc.beta = 0.0;
-        if (int r = ch->rhs_async(cc)) return fail(r, "nested operator: " + ch->err);
+    }
+    return CMDG_OK;
+}
+
+int EngineBase::run_pre_hooks_b(const RhsCtx &c)
+{
+    if (hooks.pre_rhs_handle) {
+        EngineBase *ch = hooks.pre_rhs_handle->eng;
         HIPCHK(ev_record(ch->ev_comp, ch->s_comp));
         HIPCHK(hipStreamWaitEvent(s_comp, ch->ev_comp, 0));
         const int64_t n = nreal * Np;
@@ -1409,6 +1450,17 @@ int EngineBase::run_pre_hooks(const RhsCtx &c)
     if (hooks.has_flow_deviation)
         if (int r = flow_deviation(c.Qin, 0, nreal / hooks.nvertelem)) return r;
     return CMDG_OK;
+}
+
+int EngineBase::run_pre_hooks(const RhsCtx &c)
+{
+    RhsCtx cc;
+    if (int r = run_pre_hooks_a(c, cc)) return r;
+    if (hooks.pre_rhs_handle) {
+        EngineBase *ch = hooks.pre_rhs_handle->eng;
+        if (int r = ch->rhs_async(cc)) return fail(r, "nested operator: " + ch->err);
+    }
+    return run_pre_hooks_b(c);
 }
 
 // compute_flow_deviation!(dg, ::HBModel, ::Coupled, Q, t)

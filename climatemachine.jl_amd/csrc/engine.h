@@ -40,6 +40,9 @@ struct RhsCtx {
     bool lsrk = false;         // fused update inside k_tendency
     bool update_after = false; // separate update!() after the (filtered) tendency
     double rkb_dt = 0, rka_next = 0;
+    // the law's update_auxiliary_state!(realelems) composition has run already (group_rhs runs the
+    // nested operators of a local group in lock step before segment 0)
+    bool pre_done = false;
 };
 
 // one `Filters.apply!` call site: filter + target + direction (include/cmdg.h)
@@ -328,6 +331,9 @@ struct EngineBase {
     std::vector<EngineBase *> nested_in;
     int set_hooks(const cmdg_rhs_hooks *hk);
     int run_pre_hooks(const RhsCtx &c);
+    // ... in two halves around the evaluation of the nested operator (hooks.pre_rhs_handle)
+    int run_pre_hooks_a(const RhsCtx &c, RhsCtx &nested);
+    int run_pre_hooks_b(const RhsCtx &c);
     int integrate_velocity(const double *X, int nstate, int col, int nvert, int64_t h0 = 0,
                            int64_t nh = -1);
     int flow_deviation(double *Q, int64_t h0, int64_t nh);

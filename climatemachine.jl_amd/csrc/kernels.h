@@ -42,6 +42,12 @@
 #ifndef CMDG_LAP_MINW
 #define CMDG_LAP_MINW 1
 #endif
+// paired work-groups of the tendency pass (TendencyShape<..., PAIR>, CMDG_OPT_TENDENCY_PAIRS): the
+// round-4 structural experiment, measured and rejected (profiles/r04_ab_tendency_pairs.txt), kept
+// buildable: make EXTRA=-DCMDG_TEND_PAIRS=1
+#ifndef CMDG_TEND_PAIRS
+#define CMDG_TEND_PAIRS 0
+#endif
 // tendency pass of large elements (N >= 5) in two launches, volume then interface + update
 // (see TendencyShape::SPLIT; off: measured slower than two elements per work-group), and the
 // register budgets asked for the two halves (waves per SIMD)
@@ -378,7 +384,7 @@ enum { TEND_FUSED = 0, TEND_VOLUME = 1, TEND_FACES = 2 };
 template <class P, int NQ, int NQV, bool PAIR = false>
 struct TendencyShape {
     using KD = KDims<NQ, NQV>;
-    static constexpr bool PAIRABLE = node_cache_size<P>::value == 0 && NQ == NQV;
+    static constexpr bool PAIRABLE = CMDG_TEND_PAIRS != 0 && node_cache_size<P>::value == 0 && NQ == NQV;
     static constexpr bool SPLIT = KD::Np > 125 && node_cache_size<P>::value == 0 && CMDG_TEND_SPLIT_LARGE != 0 && !PAIR;
     static constexpr int EPB = PAIR ? 2
                                     : (node_cache_size<P>::value != 0 || SPLIT

@@ -5,6 +5,7 @@
 // extrusion of the 2-D grid.  Slow work is enqueued on the slow engine's stream, barotropic
 // sub-steps on the fast engine's; events order the two around each exchange and the host never
 // waits: the second slow evaluation + update! of a stage overlap that stage's sub-steps.
+// Partitioned runs: one (slow, fast) pair per rank, see group_split_explicit01_step.
 #include <cmath>
 #include <vector>
 
@@ -115,34 +116,53 @@ int launch_status01(EngineBase *e)
 
 }  // namespace
 
-extern "C" int cmdg_split_explicit01_step(cmdg_handle slow, cmdg_handle fast, const cmdg_ocean01_desc *d,
-                                          double *Q3, double *dQ3, double *dQ2fast, double *Q2,
-                                          double *dQ2, double t, double dt, double dt_fast,
-                                          int32_t nstages, const double *rka, const double *rkb,
-                                          const double *rkc)
+// dostep!(Qslow, ::SplitExplicitLSRK2nSolver, param, time) for n (slow, fast) pairs in lock step: one
+// pair per rank.  With the RCCL transport a process drives its own pair (n = 1); handles connected
+// by cmdg_comm_connect_local (slow models, fast models and the nested continuity operators, each
+// among themselves) are driven together by one host thread.  Every exchange function acts on a
+// rank's real columns; the ghost stacks' flow deviation and kinematic pressure come from the
+// operator itself (EngineBase::rhs_segment, segment 1).
+static int group_split_explicit01_step(int n, cmdg_handle *slow, cmdg_handle *fast, const cmdg_ocean01_desc *d,
+                                       double **Q3, double **dQ3, double **dQ2fast, double **Q2,
+                                       double **dQ2, double t, double dt, double dt_fast,
+                                       int32_t nstages, const double *rka, const double *rkb,
+                                       const double *rkc)
 {
-    if (!slow || !fast || !d || !Q3 || !dQ3 || !dQ2fast || !Q2 || !dQ2 || !rka || !rkb || !rkc ||
-        nstages < 1)
-        return CMDG_ERR_INVALID;
-    DevGuard guard_(slow->eng);
-    EngineBase *S = slow->eng, *F = fast->eng;
     using B = BarotropicSE01;
     using O = OceanSE01;
+    std::vector<EngineBase *> S(n), F(n);
+    if (!slow[0]) return CMDG_ERR_INVALID;
+    DevGuard guard_(slow[0]->eng);
     auto bad = [&](const char *msg) {
-        S->fail(CMDG_ERR_INVALID, msg);
-        slow->err = S->err;
+        slow[0]->eng->fail(CMDG_ERR_INVALID, msg);
+        slow[0]->err = slow[0]->eng->err;
         return CMDG_ERR_INVALID;
     };
-    if (S->ns != O::NS || S->naux != O::NAUX || S->ngf != O::NGF || F->ns != B::NS || F->naux != B::NAUX)
-        return bad("split explicit 01: handles are not the OceanModel / BarotropicModel pair");
-    if (!S->stacked || d->nvertelem < 1 || S->nreal % d->nvertelem || F->nreal != S->nreal / d->nvertelem)
-        return bad("split explicit 01: the fast grid holds one element per stack of the slow grid");
-    if (F->Np % (S->NQ * S->NQ) || S->Np != S->NQ * S->NQ * S->NQ || !(d->H > 0) || d->add_fast_substeps < 0)
-        return bad("split explicit 01: grids / parameters");
-    if (S->communicate() || F->communicate())
-        return bad("split explicit 01: single rank only");
-    if (F->dev != S->dev)  // the fast launches and the events between the two engines assume one device
-        return bad("split explicit 01: the slow and the fast handle live on one device");
+    for (int i = 0; i < n; ++i) {
+        if (!slow[i] || !fast[i] || !Q3[i] || !dQ3[i] || !dQ2fast[i] || !Q2[i] || !dQ2[i]) return CMDG_ERR_INVALID;
+        S[i] = slow[i]->eng;
+        F[i] = fast[i]->eng;
+        if (S[i]->ns != O::NS || S[i]->naux != O::NAUX || S[i]->ngf != O::NGF || F[i]->ns != B::NS ||
+            F[i]->naux != B::NAUX)
+            return bad("split explicit 01: handles are not the OceanModel / BarotropicModel pair");
+        if (!S[i]->stacked || d->nvertelem < 1 || S[i]->nreal % d->nvertelem ||
+            F[i]->nreal != S[i]->nreal / d->nvertelem)
+            return bad("split explicit 01: the fast grid holds one element per stack of the slow grid");
+        if (F[i]->Np % (S[i]->NQ * S[i]->NQ) || S[i]->Np != S[i]->NQ * S[i]->NQ * S[i]->NQ || !(d->H > 0) ||
+            d->add_fast_substeps < 0)
+            return bad("split explicit 01: grids / parameters");
+        if (F[i]->dev != S[i]->dev)  // the fast launches and the events between the two engines assume one device
+            return bad("split explicit 01: the slow and the fast handle live on one device");
+        if (n > 1 && (S[i]->transport != TRANSPORT_LOCAL || F[i]->transport != TRANSPORT_LOCAL))
+            return bad("split explicit 01: several pairs in one call need the local transport");
+        if (!S[i]->d_Imat) {
+            if (!d->Imat) return bad("split explicit 01: Imat is NULL");
+            if (hipMalloc(&S[i]->d_Imat, sizeof(double) * S[i]->NQ * S[i]->NQ) != hipSuccess ||
+                hipMemcpy(S[i]->d_Imat, d->Imat, sizeof(double) * S[i]->NQ * S[i]->NQ, hipMemcpyHostToDevice) !=
+                    hipSuccess)
+                return bad("split explicit 01: Imat upload failed");
+        }
+    }
     // dostep!(Qfast, fast, ...) runs the FAST solver's scheme (SplitExplicitLSRK2nMethod.jl:150-165):
     // its own tableau when the caller gives one, the slow solver's otherwise
     const int nst_f = d->nstages_fast > 0 ? d->nstages_fast : nstages;
@@ -151,25 +171,23 @@ extern "C" int cmdg_split_explicit01_step(cmdg_handle slow, cmdg_handle fast, co
     const double *rkc_f = d->nstages_fast > 0 ? d->rkc_fast : rkc;
     if (d->nstages_fast < 0 || (d->nstages_fast > 0 && (!rka_f || !rkb_f || !rkc_f)))
         return bad("split explicit 01: the fast solver's tableau");
-    if (!S->d_Imat) {
-        if (!d->Imat) return bad("split explicit 01: Imat is NULL");
-        if (hipMalloc(&S->d_Imat, sizeof(double) * S->NQ * S->NQ) != hipSuccess ||
-            hipMemcpy(S->d_Imat, d->Imat, sizeof(double) * S->NQ * S->NQ, hipMemcpyHostToDevice) != hipSuccess)
-            return bad("split explicit 01: Imat upload failed");
-    }
-    const int Nij = S->NQ * S->NQ, nv = d->nvertelem, Nqk2 = F->Np / Nij, Np2 = F->Np, Np3 = S->Np;
-    const int64_t nh = F->nreal, n3 = S->nreal;
-    auto fcols = [&](double *dst, int ndst, int dcol, const double *src, int nsrc, int scol, int ncol,
+    const int Nij = S[0]->NQ * S[0]->NQ, nv = d->nvertelem, Nqk2 = F[0]->Np / Nij, Np2 = F[0]->Np, Np3 = S[0]->Np;
+    auto fcols = [&](int i, double *dst, int ndst, int dcol, const double *src, int nsrc, int scol, int ncol,
                      int op, hipStream_t st) {
+        const int64_t nh = F[i]->nreal;
+        if (nh == 0) return;
         hipLaunchKernelGGL(k01_cols, dim3(nblocks01(nh * ncol * Np2)), dim3(256), 0, st, dst, ndst, dcol,
                            src, nsrc, scol, ncol, op, Np2, nh);
     };
-    auto fail_from = [&](EngineBase *e, int r) {
-        slow->err = e->err;
+    auto fail_from = [&](std::vector<EngineBase *> &E, int r) {
+        for (int i = 0; i < n; ++i)
+            if (!E[i]->err.empty()) {
+                slow[0]->err = E[i]->err;
+                break;
+            }
         return r;
     };
-    std::vector<EngineBase *> Fv{F};
-    double *Q2v[1] = {Q2}, *dQ2v[1] = {dQ2};
+    std::vector<RhsCtx> c(n);
     for (int s = 0; s < nstages; ++s) {
         const bool first = s == 0, last = s == nstages - 1;
         const double stage_time = t + rkc[s] * dt;
@@ -188,73 +206,127 @@ extern "C" int cmdg_split_explicit01_step(cmdg_handle slow, cmdg_handle fast, co
         }
         const double fdt = fract_dt / fs2;
         double count = 0.0;
-        hipLaunchKernelGGL(k_fill_columns, dim3(nblocks01(nh * 3 * Np2)), dim3(256), 0, F->s_comp, F->aux,
-                           B::NAUX, (int)B::AUC, 3, -0.0, Np2, nh);  // U_c, eta_c (adjacent columns)
-        if (!first) {  // set fast-state to previously stored value
-            fcols(Q2, B::NS, B::ETA, F->aux, B::NAUX, B::AETAS, 1, 0, F->s_comp);
-            fcols(Q2, B::NS, B::U1, F->aux, B::NAUX, B::AUS, 2, 0, F->s_comp);
+        for (int i = 0; i < n; ++i) {
+            const int64_t nh = F[i]->nreal, n3 = S[i]->nreal;
+            if (nh > 0)
+                hipLaunchKernelGGL(k_fill_columns, dim3(nblocks01(nh * 3 * Np2)), dim3(256), 0, F[i]->s_comp,
+                                   F[i]->aux, B::NAUX, (int)B::AUC, 3, -0.0, Np2, nh);  // U_c, eta_c (adjacent columns)
+            if (!first) {  // set fast-state to previously stored value
+                fcols(i, Q2[i], B::NS, B::ETA, F[i]->aux, B::NAUX, B::AETAS, 1, 0, F[i]->s_comp);
+                fcols(i, Q2[i], B::NS, B::U1, F[i]->aux, B::NAUX, B::AUS, 2, 0, F[i]->s_comp);
+            }
+            // ---- initialize_adjustment!: dG_u = 0
+            if (n3 > 0)
+                hipLaunchKernelGGL(k_fill_columns, dim3(nblocks01(n3 * 2 * Np3)), dim3(256), 0, S[i]->s_comp,
+                                   S[i]->aux, O::NAUX, (int)O::ADGU, 2, 0.0, Np3, n3);
+            // ---- slow.rhs!(dQ2fast, Qslow, ...; increment = false)
+            c[i] = RhsCtx();
+            c[i].Qin = Q3[i];
+            c[i].t = stage_time;
+            c[i].alpha = 1.0;
+            c[i].tendency = dQ2fast[i];
+            c[i].beta = 0.0;
         }
-        // ---- initialize_adjustment!: dG_u = 0
-        hipLaunchKernelGGL(k_fill_columns, dim3(nblocks01(n3 * 2 * Np3)), dim3(256), 0, S->s_comp, S->aux,
-                           O::NAUX, (int)O::ADGU, 2, 0.0, Np3, n3);
-        // ---- slow.rhs!(dQ2fast, Qslow, ...; increment = false)
-        RhsCtx c;
-        c.Qin = Q3;
-        c.t = stage_time;
-        c.alpha = 1.0;
-        c.tendency = dQ2fast;
-        c.beta = 0.0;
-        if (int r = S->rhs_async(c)) return fail_from(S, r);
-        // ---- tendency_from_slow_to_fast! (Communication.jl:166-224)
-        if (int r = S->integrate_velocity(dQ2fast, O::NS, O::U, nv)) return fail_from(S, r);
-        if (int r = order01(S, F->s_comp, S->s_comp)) return fail_from(S, r);
-        hipLaunchKernelGGL(k_top_to_layer, dim3(nblocks01(nh * Np2)), dim3(256), 0, S->s_comp, F->aux,
-                           B::NAUX, (int)B::AGU, (const double *)S->d_flowint, Nij, S->NQ, nv, Nqk2, nh);
-        hipLaunchKernelGGL(k_column_minus_top_over_H, dim3(nblocks01(n3 * Np3)), dim3(256), 0, S->s_comp,
-                           S->aux, O::NAUX, (int)O::ADGU, (const double *)S->aux, O::NAUX, (int)O::ADGU,
-                           (const double *)S->d_flowint, d->H, Nij, S->NQ, nv, (int64_t)0, n3 / nv);
-        if (int r = order01(S, S->s_comp, F->s_comp)) return fail_from(S, r);
-        // ---- slow.rhs!(dQslow, Qslow, ...; increment = true) and update!
-        c.tendency = dQ3;
-        c.beta = 1.0;
-        if (int r = S->rhs_async(c)) return fail_from(S, r);
-        {
-            const int64_t n = (int64_t)Np3 * O::NS * n3;
-            hipLaunchKernelGGL(k_lsrk_update, dim3(nblocks01(n)), dim3(256), 0, S->s_comp, dQ3, Q3,
-                               rka[(s + 1) % nstages], rkb[s] * dt, n);
+        if (int r = group_rhs(S, c)) return fail_from(S, r);
+        for (int i = 0; i < n; ++i) {
+            const int64_t nh = F[i]->nreal, n3 = S[i]->nreal;
+            // ---- tendency_from_slow_to_fast! (Communication.jl:166-224)
+            if (int r = S[i]->integrate_velocity(dQ2fast[i], O::NS, O::U, nv)) return fail_from(S, r);
+            if (int r = order01(S[i], F[i]->s_comp, S[i]->s_comp)) return fail_from(S, r);
+            if (nh > 0) {
+                hipLaunchKernelGGL(k_top_to_layer, dim3(nblocks01(nh * Np2)), dim3(256), 0, S[i]->s_comp,
+                                   F[i]->aux, B::NAUX, (int)B::AGU, (const double *)S[i]->d_flowint, Nij,
+                                   S[i]->NQ, nv, Nqk2, nh);
+                hipLaunchKernelGGL(k_column_minus_top_over_H, dim3(nblocks01(n3 * Np3)), dim3(256), 0,
+                                   S[i]->s_comp, S[i]->aux, O::NAUX, (int)O::ADGU, (const double *)S[i]->aux,
+                                   O::NAUX, (int)O::ADGU, (const double *)S[i]->d_flowint, d->H, Nij, S[i]->NQ,
+                                   nv, (int64_t)0, n3 / nv);
+            }
+            if (int r = order01(S[i], S[i]->s_comp, F[i]->s_comp)) return fail_from(S, r);
+            // ---- slow.rhs!(dQslow, Qslow, ...; increment = true)
+            c[i].tendency = dQ3[i];
+            c[i].beta = 1.0;
+        }
+        if (int r = group_rhs(S, c)) return fail_from(S, r);
+        for (int i = 0; i < n; ++i) {  // ... and update!
+            const int64_t nn = (int64_t)Np3 * O::NS * S[i]->nreal;
+            if (nn > 0)
+                hipLaunchKernelGGL(k_lsrk_update, dim3(nblocks01(nn)), dim3(256), 0, S[i]->s_comp, dQ3[i], Q3[i],
+                                   rka[(s + 1) % nstages], rkb[s] * dt, nn);
         }
         // ---- barotropic sub-steps with cummulate_fast_solution! (Communication.jl:226-252)
         for (int sub = 1; sub <= fs3; ++sub) {
             const double fast_time = stage_time + (sub - 1) * fdt;
-            if (int r = group_lsrk_step(Fv, Q2v, dQ2v, fast_time, fdt, nst_f, rka_f, rkb_f, rkc_f))
+            if (int r = group_lsrk_step(F, Q2, dQ2, fast_time, fdt, nst_f, rka_f, rkb_f, rkc_f))
                 return fail_from(F, r);
-            if (sub >= fs1) {
-                fcols(F->aux, B::NAUX, B::AUC, Q2, B::NS, B::U1, 2, 1, F->s_comp);
-                fcols(F->aux, B::NAUX, B::AETAC, Q2, B::NS, B::ETA, 1, 1, F->s_comp);
-                count += 1.0;
+            for (int i = 0; i < n; ++i) {
+                if (sub >= fs1) {
+                    fcols(i, F[i]->aux, B::NAUX, B::AUC, Q2[i], B::NS, B::U1, 2, 1, F[i]->s_comp);
+                    fcols(i, F[i]->aux, B::NAUX, B::AETAC, Q2[i], B::NS, B::ETA, 1, 1, F[i]->s_comp);
+                }
+                if (sub == fs2) {
+                    fcols(i, F[i]->aux, B::NAUX, B::AUS, Q2[i], B::NS, B::U1, 2, 0, F[i]->s_comp);
+                    fcols(i, F[i]->aux, B::NAUX, B::AETAS, Q2[i], B::NS, B::ETA, 1, 0, F[i]->s_comp);
+                }
             }
-            if (sub == fs2) {
-                fcols(F->aux, B::NAUX, B::AUS, Q2, B::NS, B::U1, 2, 0, F->s_comp);
-                fcols(F->aux, B::NAUX, B::AETAS, Q2, B::NS, B::ETA, 1, 0, F->s_comp);
-            }
+            if (sub >= fs1) count += 1.0;
         }
         // ---- reconcile_from_fast_to_slow! (Communication.jl:254-336)
-        hipLaunchKernelGGL(k01_scale, dim3(nblocks01(nh * 3 * Np2)), dim3(256), 0, F->s_comp, F->aux,
-                           B::NAUX, (int)B::AUC, 3, 1 / count, Np2, nh);
-        if (int r = S->integrate_velocity(Q3, O::NS, O::U, nv)) return fail_from(S, r);
-        if (int r = order01(S, F->s_comp, S->s_comp)) return fail_from(S, r);
-        hipLaunchKernelGGL(k01_reconcile_layer, dim3(nblocks01(nh * Np2)), dim3(256), 0, S->s_comp, F->aux,
-                           (const double *)Q3, (const double *)S->d_flowint, d->H, (int)last, Nij, S->NQ,
-                           nv, Nqk2, nh);
-        hipLaunchKernelGGL(k01_reconcile_column, dim3(nblocks01(n3 * Np3)), dim3(256), 0, S->s_comp, Q3,
-                           (const double *)F->aux, (int)last, Nij, S->NQ, nv, Nqk2, nh);
-        if (last) {  // reset fast-state to end of time-step value
-            fcols(Q2, B::NS, B::ETA, F->aux, B::NAUX, B::AETAS, 1, 0, S->s_comp);
-            fcols(Q2, B::NS, B::U1, F->aux, B::NAUX, B::AUS, 2, 0, S->s_comp);
+        for (int i = 0; i < n; ++i) {
+            const int64_t nh = F[i]->nreal, n3 = S[i]->nreal;
+            if (nh > 0)
+                hipLaunchKernelGGL(k01_scale, dim3(nblocks01(nh * 3 * Np2)), dim3(256), 0, F[i]->s_comp, F[i]->aux,
+                                   B::NAUX, (int)B::AUC, 3, 1 / count, Np2, nh);
+            if (int r = S[i]->integrate_velocity(Q3[i], O::NS, O::U, nv)) return fail_from(S, r);
+            if (int r = order01(S[i], F[i]->s_comp, S[i]->s_comp)) return fail_from(S, r);
+            if (nh > 0) {
+                hipLaunchKernelGGL(k01_reconcile_layer, dim3(nblocks01(nh * Np2)), dim3(256), 0, S[i]->s_comp,
+                                   F[i]->aux, (const double *)Q3[i], (const double *)S[i]->d_flowint, d->H,
+                                   (int)last, Nij, S[i]->NQ, nv, Nqk2, nh);
+                hipLaunchKernelGGL(k01_reconcile_column, dim3(nblocks01(n3 * Np3)), dim3(256), 0, S[i]->s_comp,
+                                   Q3[i], (const double *)F[i]->aux, (int)last, Nij, S[i]->NQ, nv, Nqk2, nh);
+            }
+            if (last) {  // reset fast-state to end of time-step value
+                fcols(i, Q2[i], B::NS, B::ETA, F[i]->aux, B::NAUX, B::AETAS, 1, 0, S[i]->s_comp);
+                fcols(i, Q2[i], B::NS, B::U1, F[i]->aux, B::NAUX, B::AUS, 2, 0, S[i]->s_comp);
+            }
+            if (int r = order01(S[i], S[i]->s_comp, F[i]->s_comp)) return fail_from(S, r);
         }
-        if (int r = order01(S, S->s_comp, F->s_comp)) return fail_from(S, r);
     }
-    int r = launch_status01(S);
-    if (r) slow->err = S->err;
+    int r = launch_status01(S[0]);
+    if (r) slow[0]->err = S[0]->err;
     return r;
+}
+
+extern "C" int cmdg_split_explicit01_step(cmdg_handle slow, cmdg_handle fast, const cmdg_ocean01_desc *d,
+                                          double *Q3, double *dQ3, double *dQ2fast, double *Q2,
+                                          double *dQ2, double t, double dt, double dt_fast,
+                                          int32_t nstages, const double *rka, const double *rkb,
+                                          const double *rkc)
+{
+    if (!slow || !fast || !d || !Q3 || !dQ3 || !dQ2fast || !Q2 || !dQ2 || !rka || !rkb || !rkc ||
+        nstages < 1)
+        return CMDG_ERR_INVALID;
+    if (slow->eng->transport == TRANSPORT_LOCAL && slow->eng->communicate()) {
+        slow->eng->fail(CMDG_ERR_INVALID, "handles connected locally must be driven by cmdg_group_split_explicit01_step");
+        slow->err = slow->eng->err;
+        return CMDG_ERR_INVALID;
+    }
+    return group_split_explicit01_step(1, &slow, &fast, d, &Q3, &dQ3, &dQ2fast, &Q2, &dQ2, t, dt, dt_fast,
+                                       nstages, rka, rkb, rkc);
+}
+
+extern "C" int cmdg_group_split_explicit01_step(cmdg_handle *slow, cmdg_handle *fast, int32_t n,
+                                                const cmdg_ocean01_desc *d, double **Q3, double **dQ3,
+                                                double **dQ2fast, double **Q2, double **dQ2, double t,
+                                                double dt, double dt_fast, int32_t nstages,
+                                                const double *rka, const double *rkb, const double *rkc)
+{
+    if (!slow || !fast || n < 1 || !d || !Q3 || !dQ3 || !dQ2fast || !Q2 || !dQ2 || !rka || !rkb || !rkc ||
+        nstages < 1)
+        return CMDG_ERR_INVALID;
+    for (int i = 0; i < n; ++i)
+        if (!slow[i] || !fast[i]) return CMDG_ERR_INVALID;
+    return group_split_explicit01_step(n, slow, fast, d, Q3, dQ3, dQ2fast, Q2, dQ2, t, dt, dt_fast, nstages,
+                                       rka, rkb, rkc);
 }

@@ -285,8 +285,8 @@ class SplitExplicitSolver:
         # the barotropic sub-steps are a chain of small launches whose length decides the length of
         # a slow stage: their streams go first (CMDG_OPT_STREAM_PRIORITY; results do not depend on it)
         if fast_priority is None:
-            fast_priority = os.environ.get("CMDG_OCEAN_FAST_PRIORITY", "1") != "0"
-        dg_fast.set_option(_lib.OPT_STREAM_PRIORITY, int(bool(fast_priority)))
+            fast_priority = int(os.environ.get("CMDG_OCEAN_FAST_PRIORITY", "1"))
+        dg_fast.set_option(_lib.OPT_STREAM_PRIORITY, int(fast_priority))
         self.dt, self.dt_fast, self.t, self.steps = float(dt_slow), float(dt_fast), float(t0), 0
         if coefficients is None:
             ref = LSRK54CarpenterKennedy(dg_fast, Q_fast)

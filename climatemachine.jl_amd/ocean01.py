@@ -185,6 +185,16 @@ class OceanDGModel01:
         self.conti3d_dg.close()
         self.dg.close()
 
+    @staticmethod
+    def connect_local(odgs):
+        """The per-rank operators of one process (rank r = odgs[r]) through device copies: the
+        ocean operators among themselves and the continuity operators they evaluate among
+        themselves (``cmdg_group_rhs`` runs the latter in lock step inside the former's
+        ``update_auxiliary_state!``)."""
+        from . import dgmodel
+        dgmodel.connect_local([o.dg for o in odgs])
+        dgmodel.connect_local([o.conti3d_dg for o in odgs])
+
 
 class SplitExplicitLSRK2nSolver01:
     """``SplitExplicitLSRK2nSolver(slow_solver, fast_solver)`` (SplitExplicitLSRK2nMethod.jl:40-78)
@@ -231,3 +241,30 @@ class SplitExplicitLSRK2nSolver01:
         self.dg_slow.synchronize()
         self.dg_fast.synchronize()
         self.ocean_dg.conti3d_dg.synchronize()
+
+    @staticmethod
+    def group_dostep(solvers, Q_slows, Q_fasts, nsteps=1):
+        """The same step for the per-rank solvers of one process whose slow models
+        (``OceanDGModel01.connect_local``) and fast models (``dgmodel.connect_local``) are
+        connected locally: ``cmdg_group_split_explicit01_step``."""
+        from .dgmodel import _harr, _parr
+        s0 = solvers[0]
+        L, n = s0.dg_slow.L, len(solvers)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        cast = lambda a: C.cast(a, C.c_void_p)
+        slow, fast = _harr([s.dg_slow for s in solvers]), _harr([s.dg_fast for s in solvers])
+        arr = [_parr(x) for x in (Q_slows, [s.dQ_slow for s in solvers], [s.dQ2fast for s in solvers],
+                                  Q_fasts, [s.dQ_fast for s in solvers])]
+        s0.dg_slow._torch_ready()
+        for _ in range(int(nsteps)):
+            s0._lib.check(L.cmdg_group_split_explicit01_step(
+                cast(slow), cast(fast), n, C.cast(C.byref(s0.desc), C.c_void_p), *[cast(a) for a in arr],
+                s0.t, s0.dt, s0.dt_fast, len(s0.RKA), p(s0.RKA), p(s0.RKB), p(s0.RKC)),
+                s0.dg_slow.handle)
+            for s in solvers:
+                s.steps += 1
+                s.t += s.dt
+        for s in solvers:
+            s.dg_slow.synchronize()
+            s.dg_fast.synchronize()
+            s.ocean_dg.conti3d_dg.synchronize()

@@ -215,7 +215,7 @@ int cmdg_synchronize(cmdg_handle h);
  *   LDS instead of gathering it (laws with one polynomial order and no node cache; the pairs are
  *   found from vmap+ at create: faces that meet node for node).  Results are bit-identical.
  * CMDG_OPT_STREAM_PRIORITY (default 0): 1 puts both streams of the handle at the device's highest
- *   stream priority.  Meant for a handle whose launches are small and form a long dependent chain
+ *   stream priority, -1 at the lowest.  Meant for a handle whose launches are small and form a long dependent chain
  *   next to another handle's bandwidth-bound launches (the barotropic model of the split-explicit
  *   ocean, whose sub-steps decide the length of a slow stage).  The handle must be idle; results
  *   do not depend on it. */
@@ -422,7 +422,12 @@ typedef struct cmdg_rhs_hooks {
      *   column pre_rhs_src_col of its tendency goes to auxiliary column pre_rhs_dst_aux_col;
      *   then, with ops_before_gradients != 0, the integral / reverse integral / surface
      *   operations above run here instead of after the gradient pass; then the flow deviation.
-     * Single rank only (the nested operator would need its own ghost exchange).
+     * Partitioned grids: the nested operator lives on the same partition (same neighbours) and
+     * exchanges with its own communicator (RCCL: cmdg_comm_init_rccl on it too; local transport:
+     * the nested operators form a group of their own, and cmdg_group_rhs runs them in lock step
+     * between the two halves of the composition).  After the exchange of Q the operator repeats
+     * the column operators over the received face pencils of the ghost stacks (the kinematic
+     * pressure rank-boundary faces read on their plus side), as it does for the flow deviation.
      * Lifetime: the nested handle may be destroyed first -- cmdg_destroy detaches it from every
      * handle whose hooks name it; such a handle then fails every evaluation with CMDG_ERR_INVALID
      * ("the nested operator of this handle was destroyed") until cmdg_set_rhs_hooks gives it new
@@ -488,6 +493,14 @@ int cmdg_split_explicit01_step(cmdg_handle slow, cmdg_handle fast, const cmdg_oc
                                double *Q3, double *dQ3, double *dQ2fast, double *Q2, double *dQ2,
                                double t, double dt, double dt_fast, int32_t nstages,
                                const double *rka, const double *rkb, const double *rkc);
+/* the same step for the n (slow, fast) pairs of one process whose slow models, fast models and
+ * nested continuity operators are each connected by cmdg_comm_connect_local (pair i = rank i);
+ * with the RCCL transport every rank calls cmdg_split_explicit01_step on its own pair */
+int cmdg_group_split_explicit01_step(cmdg_handle *slow, cmdg_handle *fast, int32_t n,
+                                     const cmdg_ocean01_desc *d, double **Q3, double **dQ3,
+                                     double **dQ2fast, double **Q2, double **dQ2, double t, double dt,
+                                     double dt_fast, int32_t nstages, const double *rka,
+                                     const double *rkb, const double *rkc);
 
 /* update!() of the LSRK methods on the handle's real elements (LowStorageRungeKuttaMethod.jl:
  * 146-166): Q += rkb_dt * dQ; dQ *= rka_next */

@@ -125,7 +125,7 @@ def main():
             g0 = dg.query("GRAPH_STEPS")
             # (few steps: with every neighbour mapped to the rank itself the flow is not physical
             # and does not stay finite for long)
-            solver.dostep(Q, nsteps=min(args.steps, 3))
+            solver.dostep(Q, nsteps=2)          # one eager step, one replayed
             dg.synchronize()
             res.append((Q[:grid.nreal].cpu().numpy().copy(), dg.query("GRAPH_STEPS") - g0))
         # (bit equality, NaN positions included: the rehearsal's flow need not stay finite)

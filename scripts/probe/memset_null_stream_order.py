@@ -4,9 +4,10 @@ against hipStreamNonBlocking streams.  libcmdg allocated its LSRK work states la
 step with hipMalloc + hipMemset and then wrote them from its own non-blocking streams: a fill that
 lands after the first stage's stores zeroes them (EngineBase::ensure_work before round 4).
     python scripts/probe/memset_null_stream_order.py [torch|system]
-Exit code 0 and a line "ASYNC ..." / "SYNC ..." with the measured times; the overlap test counts
-bytes of a buffer that a non-blocking stream filled with 2 AFTER the host returned from
-hipMemset(buffer, 1): any byte still 1 at the end was written by the "synchronous" memset later."""
+Part 1 times the call against the device.  Part 2 reproduces the hazard deterministically: the null
+stream is kept busy (an 8 GiB fill), hipMemset(W, 1) is issued behind it and RETURNS, a non-blocking
+stream then writes W <- 2 (the consumer's first store) and finishes while the fill of W is still
+queued; at the end W holds 1: the "earlier, synchronous" fill overwrote the later store."""
 import ctypes as C
 import os
 import sys
@@ -24,28 +25,30 @@ hip.hipMemset.argtypes = [vp, C.c_int, C.c_size_t]
 hip.hipMemsetAsync.argtypes = [vp, C.c_int, C.c_size_t, vp]
 hip.hipMemcpy.argtypes = [vp, vp, C.c_size_t, C.c_int]
 hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(vp), C.c_uint]
+hip.hipStreamSynchronize.argtypes = [vp]
 assert hip.hipSetDevice(0) == 0
-n = 4 << 30
-buf, s = vp(), vp()
-assert hip.hipMalloc(C.byref(buf), n) == 0
+big_n, n = 8 << 30, 64 << 20
+big, W, s = vp(), vp(), vp()
+assert hip.hipMalloc(C.byref(big), big_n) == 0 and hip.hipMalloc(C.byref(W), n) == 0
 assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0          # hipStreamNonBlocking
-assert hip.hipMemset(buf, 0, n) == 0 and hip.hipDeviceSynchronize() == 0   # warm-up
+assert hip.hipMemset(big, 0, big_n) == 0 and hip.hipMemset(W, 0, n) == 0 and hip.hipDeviceSynchronize() == 0
 t0 = time.perf_counter()
-assert hip.hipMemset(buf, 1, n) == 0
+assert hip.hipMemset(big, 1, big_n) == 0
 t_ret = time.perf_counter() - t0
 assert hip.hipDeviceSynchronize() == 0
 t_done = time.perf_counter() - t0
-print("%s hipMemset of 4 GiB of device memory: returned after %.1f us, device done after %.1f us"
+print("%s hipMemset of 8 GiB of device memory: returned after %.1f us, device done after %.1f us"
       % ("ASYNC" if t_ret < 0.5 * t_done else "SYNC", 1e6 * t_ret, 1e6 * t_done), flush=True)
-# overlap with a non-blocking stream
-m = 1 << 30
-assert hip.hipMemset(buf, 0, n) == 0 and hip.hipDeviceSynchronize() == 0
-assert hip.hipMemset(buf, 1, n) == 0                 # "synchronous", null stream
-assert hip.hipMemsetAsync(buf, 2, m, s) == 0         # the consumer's first write, its own stream
-assert hip.hipDeviceSynchronize() == 0
-host = (C.c_ubyte * m)()
-assert hip.hipMemcpy(host, buf, m, 2) == 0
-ones = bytes(host).count(1)
-print("bytes of the first GiB left at 1 by the later-finishing hipMemset: %d of %d (%s)"
-      % (ones, m, "NOT ORDERED against the non-blocking stream" if ones else "no overlap seen this time"),
-      flush=True)
+# the hazard
+assert hip.hipMemset(big, 3, big_n) == 0             # null stream busy for ~1.4 ms
+assert hip.hipMemset(W, 1, n) == 0                   # "synchronous" fill, queued behind it; returns
+assert hip.hipMemsetAsync(W, 2, n, s) == 0           # the consumer's first store, its own stream
+assert hip.hipStreamSynchronize(s) == 0              # the consumer is done ...
+assert hip.hipDeviceSynchronize() == 0               # ... and now everything is
+host = (C.c_ubyte * n)()
+assert hip.hipMemcpy(host, W, n, 2) == 0
+b = bytes(host)
+ones, twos = b.count(1), b.count(2)
+print("W after hipMemset(W,1) [null stream] then hipMemsetAsync(W,2) [non-blocking stream]: %d bytes = 1, %d bytes = 2  -> %s"
+      % (ones, twos, "the fill landed AFTER the later store (unordered)" if ones else "ordered this time"), flush=True)
+sys.exit(0)

@@ -453,7 +453,7 @@ def bomex_setup(nx=4, ny=4, nz=8, N=4, rank=0, size=1, zmax=3000.0, L=None):
     return MO.bomex_model(zmax), grid
 
 
-def simple_box_2dt_setup(Nx=20, Ny=20, Nz=20, N=4, N_extrusion=1):
+def simple_box_2dt_setup(Nx=20, Ny=20, Nz=20, N=4, N_extrusion=1, rank=0, size=1):
     """test/Ocean/SplitExplicit/simple_box_2dt.jl:478-517: 4e6 m x 4e6 m x 1000 m box, wind
     stress 0.2 Pa, surface relaxation 20 m / day towards 10 (1 - y / Ly), no-slip coasts and
     floor (tags 1, 2), stress + forcing surface (tag 3), c_h = 1, grav from CLIMAParameters,
@@ -465,10 +465,11 @@ def simple_box_2dt_setup(Nx=20, Ny=20, Nz=20, N=4, N_extrusion=1):
     baro = O1.BarotropicModel01(model)
     x, y, z = np.linspace(0.0, Lx, Nx + 1), np.linspace(0.0, Ly, Ny + 1), np.linspace(-H, 0.0, Nz + 1)
     topl = M.StackedBrickTopology([x, y, z], periodicity=(False, False, False),
-                                  boundary=((1, 1), (1, 1), (2, 3)))
+                                  boundary=((1, 1), (1, 1), (2, 3)), rank=rank, size=size)
     grid3 = M.DiscontinuousSpectralElementGrid(topl, N)
     grid2 = O.extruded_barotropic_grid(x, y, N, periodicity=(False, False),
-                                       boundary=((1, 1), (1, 1)), N_extrusion=N_extrusion)
+                                       boundary=((1, 1), (1, 1)), N_extrusion=N_extrusion,
+                                       rank=rank, size=size)
     return model, grid3, baro, grid2
 
 

@@ -84,3 +84,109 @@ def test_simple_box_2dt_reference_table(cm, torch):
     assert worst < 50.0        # and no statistic further than 5e-11 (12-digit rows) from the table
     odg.close()
     dg2.close()
+
+
+def _partitioned_pairs(cm, torch, size, Nx, Ny, Nz, by3, by2):
+    """Per-rank (OceanDGModel01, barotropic operator) pairs of a column partition, connected
+    through the local transport; states filled from the one-rank arrays by global element id,
+    ghosts NaN (whoever reads a ghost element that was not refreshed shows up)."""
+    O1 = cm.ocean01
+    odgs, dg2s, Q3s, Q2s, grids = [], [], [], [], []
+    for r in range(size):
+        model, g3, baro, g2 = simple_box_2dt_setup(Nx, Ny, Nz, rank=r, size=size)
+        assert g2.nreal * Nz == g3.nreal
+        odg, dg2 = _device_pair(cm, model, g3, baro, g2)
+        q3 = np.full((g3.nelem, 4, g3.Np), np.nan)
+        for i, g in enumerate(g3.topology.globalelems[:g3.nreal]):
+            q3[i] = by3[int(g)]
+        q2 = np.full((g2.nelem, 3, g2.Np), np.nan)
+        for i, g in enumerate(g2.topology.globalelems[:g2.nreal]):
+            q2[i] = by2[int(g)]
+        odgs.append(odg), dg2s.append(dg2), grids.append((g3, g2))
+        Q3s.append(torch.from_numpy(q3).to("cuda:0")), Q2s.append(torch.from_numpy(q2).to("cuda:0"))
+    O1.OceanDGModel01.connect_local(odgs)
+    cm.dgmodel.connect_local(dg2s)
+    return odgs, dg2s, Q3s, Q2s, grids
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_partitioned_split_explicit01_matches_single_rank(cm, torch, size):
+    """SplitExplicit01 on a column partition (round 4): per-rank (slow, fast) pairs and their
+    nested continuity operators through the local transport, cmdg_group_split_explicit01_step,
+    against the one-rank run on the 3 x 3 x 3 box.  The nested operator exchanges Q for itself;
+    the flow deviation and the kinematic pressure of the ghost stacks are integrated from the
+    received face pencils, so the result does not depend on the partition."""
+    O1 = cm.ocean01
+    model, g3, baro, g2 = simple_box_2dt_setup(3, 3, 3)
+    odg, dg2 = _device_pair(cm, model, g3, baro, g2)
+    rng = np.random.default_rng(5)
+    Q3h = model.init_state_prognostic(g3, odg.dg.state_auxiliary.cpu().numpy(), 0.0)
+    Q3h[:, 0:2] += 0.05 * rng.standard_normal(Q3h[:, 0:2].shape)      # u, v: a flow to couple
+    Q3h[:, 3] += 0.1 * rng.standard_normal(Q3h[:, 3].shape)           # theta
+    Q2h = baro.init_state_prognostic(g2, dg2.state_auxiliary.cpu().numpy(), 0.0)
+    by3 = {int(g): Q3h[i] for i, g in enumerate(g3.topology.globalelems[:g3.nreal])}
+    by2 = {int(g): Q2h[i] for i, g in enumerate(g2.topology.globalelems[:g2.nreal])}
+    Q3, Q2 = torch.from_numpy(Q3h.copy()).to("cuda:0"), torch.from_numpy(Q2h.copy()).to("cuda:0")
+    se = O1.SplitExplicitLSRK2nSolver01(odg, dg2, Q3, Q2, 5400.0, 240.0)
+    se.dostep(Q3, Q2, 2)
+    ref3 = {int(g): Q3[i].cpu().numpy() for i, g in enumerate(g3.topology.globalelems[:g3.nreal])}
+    ref2 = {int(g): Q2[i].cpu().numpy() for i, g in enumerate(g2.topology.globalelems[:g2.nreal])}
+    refa = {int(g): odg.dg.state_auxiliary[i].cpu().numpy()
+            for i, g in enumerate(g3.topology.globalelems[:g3.nreal])}
+    odgs, dg2s, Q3s, Q2s, grids = _partitioned_pairs(cm, torch, size, 3, 3, 3, by3, by2)
+    solvers = [O1.SplitExplicitLSRK2nSolver01(o, d2, q3, q2, 5400.0, 240.0)
+               for o, d2, q3, q2 in zip(odgs, dg2s, Q3s, Q2s)]
+    torch.cuda.synchronize()
+    O1.SplitExplicitLSRK2nSolver01.group_dostep(solvers, Q3s, Q2s, 2)
+    worst = 0.0
+    for (gr3, gr2), o, q3, q2 in zip(grids, odgs, Q3s, Q2s):
+        q3n, q2n, an = q3.cpu().numpy(), q2.cpu().numpy(), o.dg.state_auxiliary.cpu().numpy()
+        for i, g in enumerate(gr3.topology.globalelems[:gr3.nreal]):
+            for s in range(4):
+                worst = max(worst, np.abs(q3n[i, s] - ref3[int(g)][s]).max() / max(np.abs(ref3[int(g)][s]).max(), 1e-3))
+            for s in range(8):
+                worst = max(worst, np.abs(an[i, s] - refa[int(g)][s]).max() / max(np.abs(refa[int(g)][s]).max(), 1e-3))
+        for i, g in enumerate(gr2.topology.globalelems[:gr2.nreal]):
+            for s in range(3):
+                worst = max(worst, np.abs(q2n[i, s] - ref2[int(g)][s]).max() / max(np.abs(ref2[int(g)][s]).max(), 1e-3))
+    assert observe("se01:5 partitioned vs one rank", worst) < 1e-12
+    for o in odgs + [odg]:
+        o.close()
+    for d in dg2s + [dg2]:
+        d.close()
+
+
+def test_simple_box_2dt_reference_table_on_two_ranks(cm, torch):
+    """The reference's regression table again, the box cut in two (local transport): the 112
+    statistics are taken over both ranks' real elements."""
+    O1 = cm.ocean01
+    model, g3, baro, g2 = simple_box_2dt_setup()
+    odg, dg2 = _device_pair(cm, model, g3, baro, g2)
+    Q3h = model.init_state_prognostic(g3, odg.dg.state_auxiliary.cpu().numpy(), 0.0)
+    Q2h = baro.init_state_prognostic(g2, dg2.state_auxiliary.cpu().numpy(), 0.0)
+    by3 = {int(g): Q3h[i] for i, g in enumerate(g3.topology.globalelems[:g3.nreal])}
+    by2 = {int(g): Q2h[i] for i, g in enumerate(g2.topology.globalelems[:g2.nreal])}
+    odg.close(), dg2.close()
+    odgs, dg2s, Q3s, Q2s, grids = _partitioned_pairs(cm, torch, 2, 20, 20, 20, by3, by2)
+    runtime, dt_slow = 5 * 24 * 3600.0, 5400.0
+    n = int(np.ceil(runtime / dt_slow))
+    solvers = [O1.SplitExplicitLSRK2nSolver01(o, d2, q3, q2, runtime / n, 240.0)
+               for o, d2, q3, q2 in zip(odgs, dg2s, Q3s, Q2s)]
+    torch.cuda.synchronize()
+    O1.SplitExplicitLSRK2nSolver01.group_dostep(solvers, Q3s, Q2s, n)
+    parts = []
+    for (gr3, gr2), o, d2, q3, q2 in zip(grids, odgs, dg2s, Q3s, Q2s):
+        nr = gr3.nreal
+        parts.append(simple_box_2dt_fields(q3.cpu().numpy()[:nr], o.dg.state_auxiliary.cpu().numpy()[:nr],
+                                           q2.cpu().numpy(), d2.state_auxiliary.cpu().numpy(), gr2))
+    f = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    rep = []
+    try:
+        worst, margin = check_statecheck_table(GOLD["varr"], GOLD["parr"], f, relaxed=RELAXED, report=rep)
+    finally:
+        print("\n".join(rep))
+    assert worst < 50.0
+    for o in odgs:
+        o.close()
+    for d in dg2s:
+        d.close()
