@@ -410,9 +410,9 @@ def timed_run(cm, dg, law, grid, dt, steps, warmup, sync_all, distributed, dev):
     return Q, solver, el
 
 
-PMC_FILES = {("heldsuarez", 43200): "r03_heldsuarez_n30_pmc_hbm_per_launch.json",
-             ("risingbubble", 8000): "r03_risingbubble_8000_pmc_hbm_per_launch.json",
-             ("bomex", 8192): "r03_bomex_n6_8192_pmc_hbm_per_launch.json"}
+PMC_FILES = {("heldsuarez", 43200): "r04_heldsuarez_n30_pmc_hbm_per_launch.json",
+             ("risingbubble", 8000): "r04_risingbubble_8000_pmc_hbm_per_launch.json",
+             ("bomex", 8192): "r04_bomex_n6_8192_pmc_hbm_per_launch.json"}
 
 
 def kernel_source_digest():
@@ -470,6 +470,13 @@ def measure(cm, args, workload_args, rank, world, distributed, dev, with_halo):
         dist.broadcast(uid, 0)
         dg.comm_init_rccl(uid.cpu().numpy().tobytes(), rank, world)
         dg.comm_selftest()
+    # opt-in: one recorded step replayed (CMDG_OPT_STEP_GRAPH) / enqueued by the handle's own thread
+    # (CMDG_OPT_ASYNC_RUN).  The default stays eager for handles that exchange: the capture with
+    # RCCL groups in it has only ever run with a rank as its own peer.
+    if args.step_graph:
+        dg.set_option(cm._lib.OPT_STEP_GRAPH, 1)
+    if args.async_run:
+        dg.set_option(cm._lib.OPT_ASYNC_RUN, 1)
     step_filter = None
     if args.filter:
         assert args.workload in ("heldsuarez", "bomex")
@@ -542,7 +549,9 @@ def measure(cm, args, workload_args, rank, world, distributed, dev, with_halo):
                     "neighbours": [int(r) for r in grid.nabrtorank],
                     "send_nodes": int(len(grid.vmapsend)),
                     "exchange": {k.lower(): dg.query(k) for k in
-                                 ("DIRECT_SEND", "DIRECT_RECV", "HALO_PIPELINE")}}
+                                 ("DIRECT_SEND", "DIRECT_RECV", "HALO_PIPELINE")},
+                    "step_graph": bool(args.step_graph), "async_run": bool(args.async_run),
+                    "graph_steps_replayed": int(dg.query("GRAPH_STEPS"))}
             for key, name in (("TRANSPORT", "rccl_group"), ("HALO_EXPOSED", "exposed")):
                 ms, n = dg.profile_get(key)
                 if n:
@@ -698,6 +707,10 @@ def parse_args(argv):
                     help="heldsuarez: exponential filter of the perturbations after every step "
                          "(experiments/AtmosGCM/heldsuarez.jl:261-272); off for the headline "
                          "metric, which is the RHS + LSRK path alone")
+    ap.add_argument("--step-graph", action="store_true",
+                    help="record one LSRK step into a HIP graph and replay it (CMDG_OPT_STEP_GRAPH)")
+    ap.add_argument("--async-run", action="store_true",
+                    help="the handle's own thread enqueues the run (CMDG_OPT_ASYNC_RUN)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="time without per-kernel HIP events")
     ap.add_argument("--dry-launch", action="store_true",

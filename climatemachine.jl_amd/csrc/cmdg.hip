@@ -111,30 +111,13 @@ int dbg_sync()
     return v;
 }
 
-unsigned ev_flags()
-{
-    static const unsigned v = [] {
-        const char *p = getenv("CMDG_DBG_EVFLAGS");
-        return (p && !strcmp(p, "timing")) ? 0u : (unsigned)hipEventDisableTiming;
-    }();
-    return v;
-}
-hipError_t ev_record(hipEvent_t &e, hipStream_t s)
-{
-    static const bool ring = [] {
-        const char *p = getenv("CMDG_DBG_EVRING");
-        return p && *p == '1';
-    }();
-    if (ring) {  // (debugging only: the replaced events are leaked)
-        hipEvent_t n = nullptr;
-        if (hipEventCreateWithFlags(&n, ev_flags()) == hipSuccess) e = n;
-    }
-    return hipEventRecord(e, s);
-}
+hipError_t ev_record(hipEvent_t &e, hipStream_t s) { return hipEventRecord(e, s); }
 
 // ---------------------------------------------------------------------------------
 EngineBase::~EngineBase()
 {
+    delete worker;  // (drains its queue first)
+    worker = nullptr;
     if (s_comp) hipStreamSynchronize(s_comp);
     if (s_comm) hipStreamSynchronize(s_comm);
     prof_collect();
@@ -251,12 +234,12 @@ int EngineBase::init(const cmdg_desc *d)
             HIPCHK(hipStreamCreateWithFlags(&s_comm, hipStreamNonBlocking));
     }
     for (int i = 0; i < 2; ++i) {
-        HIPCHK(hipEventCreateWithFlags(&ev_int[i], ev_flags()));
-        HIPCHK(hipEventCreateWithFlags(&ev_ext[i], ev_flags()));
+        HIPCHK(hipEventCreateWithFlags(&ev_int[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_ext[i], hipEventDisableTiming));
     }
-    HIPCHK(hipEventCreateWithFlags(&gev_fork, ev_flags()));
+    HIPCHK(hipEventCreateWithFlags(&gev_fork, hipEventDisableTiming));
     if (const char *v = getenv("CMDG_STEP_GRAPH")) step_graph = *v && *v != '0';
-    HIPCHK(hipEventCreateWithFlags(&ev_comp, ev_flags()));
+    HIPCHK(hipEventCreateWithFlags(&ev_comp, hipEventDisableTiming));
     HIPCHK(hipMalloc(&d_D, sizeof(double) * NQ * NQ));
     HIPCHK(hipMemcpy(d_D, d->D, sizeof(double) * NQ * NQ, hipMemcpyHostToDevice));
     g.D = d_D;
@@ -325,9 +308,9 @@ int EngineBase::init(const cmdg_desc *d)
         for (auto &s : slot) {
             HIPCHK(hipMalloc(&s.sendbuf, sizeof(double) * slot_nvar_max * std::max<int64_t>(nvmapsend, 1)));
             HIPCHK(hipMalloc(&s.recvbuf, sizeof(double) * slot_nvar_max * std::max<int64_t>(nvmaprecv, 1)));
-            HIPCHK(hipEventCreateWithFlags(&s.ev_packed, ev_flags()));
-            HIPCHK(hipEventCreateWithFlags(&s.ev_done, ev_flags()));
-            HIPCHK(hipEventCreateWithFlags(&s.ev_pulled, ev_flags()));
+            HIPCHK(hipEventCreateWithFlags(&s.ev_packed, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&s.ev_pulled, hipEventDisableTiming));
         }
     }
     HIPCHK(hipMalloc(&d_partial, sizeof(double) * 1024));
@@ -340,27 +323,6 @@ int EngineBase::init(const cmdg_desc *d)
     if (int r = build_pairs()) return r;
     if (int r = init_derived()) return r;
     HIPCHK(hipStreamSynchronize(s_comp));  // the fills of alloc0 have run
-    // CMDG_DBG_INIT=<bitmask> (localising the first-use failure of priority halo streams):
-    //   1 prime both streams (a memset node each, then wait)   2 zero the halo buffers
-    //   4 allocate the LSRK work states now                     8 device-wide synchronize
-    static const int dbg_init = [] {
-        const char *p = getenv("CMDG_DBG_INIT");
-        return p ? atoi(p) : 0;
-    }();
-    if (dbg_init & 1) {
-        HIPCHK(hipMemsetAsync(d_partial, 0, 8, s_comp));
-        HIPCHK(hipMemsetAsync(d_partial + 8, 0, 8, s_comm));
-        HIPCHK(hipStreamSynchronize(s_comp));
-        HIPCHK(hipStreamSynchronize(s_comm));
-    }
-    if ((dbg_init & 2) && communicate())
-        for (auto &sl : slot) {
-            HIPCHK(hipMemset(sl.sendbuf, 0, sizeof(double) * slot_nvar_max * std::max<int64_t>(nvmapsend, 1)));
-            HIPCHK(hipMemset(sl.recvbuf, 0, sizeof(double) * slot_nvar_max * std::max<int64_t>(nvmaprecv, 1)));
-        }
-    if (dbg_init & 4)
-        if (int r = ensure_work()) return r;
-    if (dbg_init & 8) HIPCHK(hipDeviceSynchronize());
     return CMDG_OK;
 }
 
@@ -442,18 +404,10 @@ int EngineBase::ensure_work()
             // for device memory and, on the null stream, unordered against the non-blocking
             // streams below, so it could land AFTER the first stages had stored into W and zero
             // them (the "priority stream ordering failure" of round 3: high-priority halo streams
-            // merely let the stage kernels overtake the fill; CMDG_DBG_WORK_MEMSET=null restores it).
+            // merely let the stage kernels overtake the fill; scripts/probe/memset_null_stream_order.py).
             HIPCHK(hipMalloc(&W[i], sizeof(double) * n));
-            static const bool legacy = [] {
-                const char *p = getenv("CMDG_DBG_WORK_MEMSET");
-                return p && !strcmp(p, "null");
-            }();
-            if (legacy) {
-                HIPCHK(hipMemset(W[i], 0, sizeof(double) * n));
-            } else {
-                HIPCHK(hipMemsetAsync(W[i], 0, sizeof(double) * n, s_comp));
-                HIPCHK(hipStreamSynchronize(s_comp));
-            }
+            HIPCHK(hipMemsetAsync(W[i], 0, sizeof(double) * n, s_comp));
+            HIPCHK(hipStreamSynchronize(s_comp));
         }
     return CMDG_OK;
 }
@@ -1146,8 +1100,8 @@ int EngineBase::capture_step(double *Q, double *dQ, double dt, int nstages, cons
     double *Qs[1] = {Q}, *dQs[1] = {dQ};
     if (4 * nstages + 1 > NGEV) return fail(CMDG_ERR_UNSUPPORTED, "step graph: too many stages");
     for (int i = 0; i < NGEV; ++i) {  // (created on first use: most handles never capture)
-        if (!gev_int[i]) HIPCHK(hipEventCreateWithFlags(&gev_int[i], ev_flags()));
-        if (!gev_ext[i]) HIPCHK(hipEventCreateWithFlags(&gev_ext[i], ev_flags()));
+        if (!gev_int[i]) HIPCHK(hipEventCreateWithFlags(&gev_int[i], hipEventDisableTiming));
+        if (!gev_ext[i]) HIPCHK(hipEventCreateWithFlags(&gev_ext[i], hipEventDisableTiming));
     }
     capturing = true;
     cap_interior = cap_exterior = cap_pass = 0;
@@ -1859,14 +1813,37 @@ int cmdg_lsrk_run(cmdg_handle h, double *Q, double *dQ, double t, double dt, int
                   int32_t nstages, const double *rka, const double *rkb, const double *rkc)
 {
     if (!h || !Q || !dQ || !rka || !rkb || !rkc) return CMDG_ERR_INVALID;
-    DevGuard guard_(h->eng);
-    return set_err(h, h->eng->run_steps(Q, dQ, t, dt, nsteps, nstages, rka, rkb, rkc));
+    EngineBase *e = h->eng;
+    if (e->worker && nstages >= 1 && nstages <= 16) {  // CMDG_OPT_ASYNC_RUN: the handle's own thread enqueues
+        std::vector<double> a(rka, rka + nstages), b(rkb, rkb + nstages), c(rkc, rkc + nstages);
+        e->worker->submit([=]() {
+            DevGuard guard_(e);
+            const int r = e->run_steps(Q, dQ, t, dt, nsteps, nstages, a.data(), b.data(), c.data());
+            if (r) {
+                std::lock_guard<std::mutex> lk(e->worker->m);
+                if (e->worker->deferred_err.empty()) e->worker->deferred_err = e->err;
+            }
+            return r;
+        });
+        return CMDG_OK;
+    }
+    DevGuard guard_(e);
+    return set_err(h, e->run_steps(Q, dQ, t, dt, nsteps, nstages, rka, rkb, rkc));
 }
 
 int cmdg_synchronize(cmdg_handle h)
 {
     if (!h) return CMDG_ERR_INVALID;
-    DevGuard guard_(h->eng);
+    DevGuard guard_(h->eng);  // (waits for deferred runs)
+    if (h->eng->worker) {     // a deferred run that failed reports here
+        std::lock_guard<std::mutex> lk(h->eng->worker->m);
+        if (const int r = h->eng->worker->deferred_rc) {
+            h->eng->err = h->eng->worker->deferred_err;
+            h->eng->worker->deferred_rc = 0;
+            h->eng->worker->deferred_err.clear();
+            return set_err(h, r);
+        }
+    }
     return set_err(h, h->eng->synchronize());
 }
 
@@ -1896,6 +1873,16 @@ int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value)
         e->graph_failed = false;
         return CMDG_OK;
     case CMDG_OPT_STREAM_PRIORITY: return set_err(h, e->set_stream_priority(value));
+    case CMDG_OPT_ASYNC_RUN:
+        if (value && !e->worker) {
+            e->worker = new (std::nothrow) RunWorker();
+            if (!e->worker) return set_err(h, e->fail(CMDG_ERR_INVALID, "async run: out of memory"));
+            e->worker->start();
+        } else if (!value && e->worker) {
+            delete e->worker;  // (idle: DevGuard waited)
+            e->worker = nullptr;
+        }
+        return CMDG_OK;
     case CMDG_OPT_TENDENCY_PAIRS:
         if (int r = e->synchronize()) return set_err(h, r);
         e->drop_graph();

@@ -7,7 +7,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cmdg.h"
@@ -67,10 +72,7 @@ void roctx_pop();
 //   64 interior_begin / exterior_begin         128 the join at the end of segment 5
 //   256 device synchronize before every group_rhs   512 device synchronize after every segment
 int dbg_sync();
-// CMDG_DBG_EVRING=1: every record takes a fresh event (never re-recorded);
-// CMDG_DBG_EVFLAGS=timing: events are created without hipEventDisableTiming
 hipError_t ev_record(hipEvent_t &e, hipStream_t s);
-unsigned ev_flags();
 struct Range {
     explicit Range(const char *name) { roctx_push(name); }
     ~Range() { roctx_pop(); }
@@ -84,7 +86,69 @@ struct ProfRec {
     bool clamp;  // record max(0, elapsed): e1 may precede e0 (exposed halo time)
 };
 
+// CMDG_OPT_ASYNC_RUN: cmdg_lsrk_run hands the run to a thread of the handle's own and returns; the
+// caller's thread is not the one that spends a millisecond per step inside hipGraphLaunch (or
+// posting RCCL groups).  One job at a time, in order; every other ABI entry of the handle first
+// waits until the worker is idle (DevGuard), so the handle is still driven by one thread at a time.
+// A failure of a deferred run is reported by the next cmdg_synchronize.
+struct RunWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<int()>> jobs;
+    bool stop = false, busy = false;
+    int deferred_rc = 0;
+    std::string deferred_err;
+    std::thread::id tid;
+    void start()
+    {
+        th = std::thread([this] {
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                cv.wait(lk, [this] { return stop || !jobs.empty(); });
+                if (jobs.empty()) return;  // (stop, drained)
+                auto job = std::move(jobs.front());
+                jobs.pop_front();
+                busy = true;
+                lk.unlock();
+                const int r = job();
+                lk.lock();
+                busy = false;
+                if (r && !deferred_rc) deferred_rc = r;
+                cv.notify_all();
+            }
+        });
+        tid = th.get_id();
+    }
+    void submit(std::function<int()> f)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            jobs.push_back(std::move(f));
+        }
+        cv.notify_all();
+    }
+    void wait_idle()
+    {
+        if (std::this_thread::get_id() == tid) return;  // (the worker's own calls)
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return jobs.empty() && !busy; });
+    }
+    ~RunWorker()
+    {
+        if (th.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(m);
+                stop = true;
+            }
+            cv.notify_all();
+            th.join();
+        }
+    }
+};
+
 struct EngineBase {
+    RunWorker *worker = nullptr;  // CMDG_OPT_ASYNC_RUN
     // ---- configuration (copied from cmdg_desc) ---------------------------------------
     int NQ = 0, NQV = 0, Np = 0, Nfp = 0;  // horizontal / vertical points per direction
     int64_t nreal = 0, nghost = 0, nelem = 0;
@@ -368,6 +432,7 @@ struct DevGuard {
     bool changed = false;
     explicit DevGuard(const EngineBase *e)
     {
+        if (e->worker) e->worker->wait_idle();  // deferred runs of this handle come first
         if (hipGetDevice(&prev) == hipSuccess && prev != e->dev)
             changed = hipSetDevice(e->dev) == hipSuccess;
     }

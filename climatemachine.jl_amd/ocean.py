@@ -282,11 +282,17 @@ class SplitExplicitSolver:
         import ctypes as C
         import os
         self.dg_slow, self.dg_fast = dg_slow, dg_fast
-        # the barotropic sub-steps are a chain of small launches whose length decides the length of
-        # a slow stage: their streams go first (CMDG_OPT_STREAM_PRIORITY; results do not depend on it)
+        # The slow model's stream is the critical path of a slow step (it is never idle,
+        # profiles/r04_ocean_timeline.txt) and its kernels run 30-55 % longer while a burst of
+        # barotropic launches shares the CUs with them; the bursts themselves are hidden behind
+        # the stage's second slow evaluation.  The barotropic streams therefore yield: lowest
+        # stream priority (measured: 11.63 ms per slow step against 11.84 at the default and 11.81 at
+        # the highest; the two models on disjoint compute units: 13.7 - 22.9 ms,
+        # profiles/r04_ab_ocean_cu_partition.txt).  CMDG_OCEAN_FAST_PRIORITY overrides.
         if fast_priority is None:
-            fast_priority = int(os.environ.get("CMDG_OCEAN_FAST_PRIORITY", "1"))
+            fast_priority = int(os.environ.get("CMDG_OCEAN_FAST_PRIORITY", "-1"))
         dg_fast.set_option(_lib.OPT_STREAM_PRIORITY, int(fast_priority))
+
         self.dt, self.dt_fast, self.t, self.steps = float(dt_slow), float(dt_fast), float(t0), 0
         if coefficients is None:
             ref = LSRK54CarpenterKennedy(dg_fast, Q_fast)

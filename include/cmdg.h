@@ -187,7 +187,12 @@ int cmdg_synchronize(cmdg_handle h);
  *   state_gradient_flux and of the hyperdiffusion arrays are NOT refreshed.  Results are
  *   bit-identical.  1 restores begin/end_ghost_exchange! as the reference runs them
  *   (kernel_fillsendbuf! / kernel_transferrecvbuf! around every exchange, MPIStateArrays.jl:411-483),
- *   for callers that read ghost elements after an evaluation.  cmdg_halo_begin/end always do.
+ *   for callers that read ghost elements after an evaluation (diagnostics, output, a Courant
+ *   number over ghosts).  cmdg_halo_begin/end always do.  cmdg_query(CMDG_Q_DIRECT_RECV) says
+ *   which mode an evaluation runs in: it turns itself off when hooks or a nodal
+ *   update_auxiliary_state! kernel read ghost elements.  Wire format: the reference's (nstate,
+ *   nvmap) state-fastest buffers, with one exception in the default mode -- of Qhypervisc_div's
+ *   nhyp columns only the ngl the Laplacian pass writes (and the next pass reads) travel.
  * CMDG_OPT_HALO_PIPELINE (default 1): handles whose exchanges run direct both ways launch the
  *   exterior element list of every pass on the halo stream, between the exchange it waits for
  *   and the exchange it feeds (a chain without event hops), and the interior list on the compute
@@ -214,6 +219,13 @@ int cmdg_synchronize(cmdg_handle h);
  *   horizontally adjacent elements two to a work-group and reads the xi1 face they share out of
  *   LDS instead of gathering it (laws with one polynomial order and no node cache; the pairs are
  *   found from vmap+ at create: faces that meet node for node).  Results are bit-identical.
+ * CMDG_OPT_ASYNC_RUN (default 0): cmdg_lsrk_run hands the run to a thread the handle owns and
+ *   returns at once (the tableau is copied, Q and dQ must stay valid): the calling thread is not the
+ *   one that spends ~1 ms per step of a partitioned run inside hipGraphLaunch or posting RCCL
+ *   groups.  Runs execute in order; every other entry point of the handle first waits until that
+ *   thread is idle, so the handle is still driven by one thread at a time; a deferred run that
+ *   failed is reported by the next cmdg_synchronize.  Same launches in the same order: results
+ *   are bit-identical.
  * CMDG_OPT_STREAM_PRIORITY (default 0): 1 puts both streams of the handle at the device's highest
  *   stream priority, -1 at the lowest.  Meant for a handle whose launches are small and form a long dependent chain
  *   next to another handle's bandwidth-bound launches (the barotropic model of the split-explicit
@@ -222,7 +234,7 @@ int cmdg_synchronize(cmdg_handle h);
 enum {
     CMDG_OPT_KEEP_GRADFLUX = 1, CMDG_OPT_STACK_HEIGHT = 2, CMDG_OPT_REFERENCE_HALO = 3,
     CMDG_OPT_HALO_PIPELINE = 4, CMDG_OPT_STEP_GRAPH = 5, CMDG_OPT_STREAM_PRIORITY = 6,
-    CMDG_OPT_TENDENCY_PAIRS = 7
+    CMDG_OPT_TENDENCY_PAIRS = 7, CMDG_OPT_ASYNC_RUN = 8
 };
 int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value);
 

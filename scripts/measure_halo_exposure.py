@@ -39,6 +39,8 @@ def main():
                     help="pack / unpack kernels around every exchange (CMDG_OPT_REFERENCE_HALO)")
     ap.add_argument("--step-graph", action="store_true",
                     help="record one step into a HIP graph and replay it (CMDG_OPT_STEP_GRAPH)")
+    ap.add_argument("--async-run", action="store_true",
+                    help="the handle's own thread enqueues the run (CMDG_OPT_ASYNC_RUN)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="interior and exterior launches on one stream (CMDG_OPT_HALO_PIPELINE = 0)")
     args = ap.parse_args()
@@ -69,6 +71,8 @@ def main():
         dg.set_option(cm._lib.OPT_HALO_PIPELINE, 0)
     if args.step_graph:
         dg.set_option(cm._lib.OPT_STEP_GRAPH, 1)
+    if args.async_run:
+        dg.set_option(cm._lib.OPT_ASYNC_RUN, 1)
     modes = {k: dg.query(k) for k in ("DIRECT_SEND", "DIRECT_RECV", "HALO_PIPELINE")}
     Q = dg.init_ode_state(0.0)
     solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
@@ -104,6 +108,9 @@ def main():
            "ms_per_step_runs": [1e3 * r / args.steps for r in runs],
            "host_enqueue_ms_per_step": 1e3 * min(enq) / args.steps,
            "step_graph": bool(args.step_graph), "graph_steps_replayed": int(graph_steps),
+           "async_run": bool(args.async_run),
+           "host_enqueue_is": "the caller's thread inside cmdg_lsrk_run" + (
+               " (the run itself is enqueued by the handle's own thread)" if args.async_run else ""),
            "host_rccl_post_us_per_exchange": 1e-3 * (h1[0] - h0[0]) / max(h1[1] - h0[1], 1), "kernels": {}}
     for k in ("GRADIENTS", "GRADIENTS_EXT", "DIVGRAD", "DIVGRAD_EXT", "GRADLAP", "GRADLAP_EXT", "TENDENCY",
               "TENDENCY_EXT", "PACK", "TRANSPORT", "UNPACK", "HALO_EXPOSED"):

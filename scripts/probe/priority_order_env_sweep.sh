@@ -1,6 +1,9 @@
 #!/bin/bash
 # Second localisation pass for the priority ordering failure: scripts/probe/priority_order_diag.py under
 # runtime / library debug settings, one fresh process each.  usage: ... [outdir]
+# RECORD of what was run in round 4 (profiles/r04_priority_env_sweep.txt): the CMDG_DBG_INIT /
+# CMDG_DBG_EVRING / CMDG_DBG_EVFLAGS knobs it sets existed only in the library of commit 4a7157d and
+# were removed with the fix; on the current library every line reports three OK trials.
 OUT=${1:-gpurun_out/prio_env}
 mkdir -p "$OUT"
 : > "$OUT/summary.txt"

@@ -1,0 +1,13 @@
+# round-4 closing pass, part B: the other workloads' profile sets and bench lines
+mkdir -p gpurun_out/r4z
+bash scripts/profile_bench.sh r04_risingbubble_8000 "--workload risingbubble --steps 20 --warmup 5" 2>&1 | tail -4
+bash scripts/profile_bench.sh r04_bomex_n6_8192 "--workload bomex --steps 10 --warmup 3" 2>&1 | tail -4
+python bench.py --workload bomex --bomex-ne 32 --steps 5 --warmup 2 --no-cpu > gpurun_out/r04_bench_bomex_n6_65536.json 2> gpurun_out/r4z/bomex65536.err; tail -c 300 gpurun_out/r04_bench_bomex_n6_65536.json
+python bench.py --workload ocean-split-explicit --steps 10 --warmup 3 > gpurun_out/r04_bench_ocean_48x48x16.json 2> gpurun_out/r4z/ocean.err; python -c "
+import json
+d=json.loads(open('gpurun_out/r04_bench_ocean_48x48x16.json').read().strip().splitlines()[-1]); print('ocean', d['ms_per_step'], d.get('cpu_baseline'))
+"
+python bench.py --workload advdiff-brick --steps 20 --warmup 5 --no-cpu > gpurun_out/r04_bench_advdiff_ne32.json 2> gpurun_out/r4z/advdiff.err; python -c "
+import json
+d=json.loads(open('gpurun_out/r04_bench_advdiff_ne32.json').read().strip().splitlines()[-1]); print('advdiff', d['ms_per_step'], d['value'])
+"

@@ -295,3 +295,39 @@ def test_step_graph_is_recorded_again_after_an_option_changes_the_launches(cm, t
     (Qe, ge, _, ne), (Qg, gg, n0, n1) = res
     assert ne == 0 and n0 == 2 and n1 == 4
     assert np.abs(ge).max() > 0 and np.array_equal(ge, gg) and np.array_equal(Qe, Qg)
+
+
+def test_async_run_equals_the_callers_own_run(cm, torch):
+    """CMDG_OPT_ASYNC_RUN: cmdg_lsrk_run hands the run to the handle's own thread and returns;
+    the next entry point waits for it.  Same launches in the same order: same bits, with and
+    without the recorded step, with and without neighbours (RCCL, the rank as its own peer);
+    two runs queued back to back execute in order; an option set in between waits for them."""
+    from helpers import pseudo1d_setup
+    from test_gpu_halo import _self_neighbour_grid
+    for neighbours in (False, True):
+        out = []
+        for asyn, graph in ((0, 0), (1, 0), (1, 1)):
+            if neighbours:
+                grid = _self_neighbour_grid(cm, 0, 2)
+                grid.nabrtorank = [0] * len(grid.nabrtorank)
+                dg = cm.dgmodel.DGModel(pseudo1d_setup()[0], grid, direction=0)
+                dg.comm_init_rccl(cm.dgmodel.rccl_unique_id(), 0, 1)
+                dt = 1e-4
+            else:
+                law, grid, dt = pseudo1d_setup(direction=0)
+                dg = cm.dgmodel.DGModel(law, grid, direction=0)
+            dg.set_option(cm._lib.OPT_STEP_GRAPH, graph)
+            dg.set_option(cm._lib.OPT_ASYNC_RUN, asyn)
+            Q = dg.init_ode_state(0.0)
+            solver = cm.odesolvers.LSRK54CarpenterKennedy(dg, Q, dt=dt)
+            solver.dostep(Q, nsteps=4)           # (returns at once: enqueued by the caller or handed over)
+            solver.dostep(Q, nsteps=3)
+            dg.set_option(cm._lib.OPT_KEEP_GRADFLUX, 0)      # an entry point in between: waits
+            dg.synchronize()
+            if graph:
+                assert dg.query("GRAPH_STEPS") == 5
+            out.append(Q[:grid.nreal].cpu().numpy().copy())
+            dg.set_option(cm._lib.OPT_ASYNC_RUN, 0)
+            dg.close()
+        assert np.isfinite(out[0]).all() and np.abs(out[0]).max() > 0
+        assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
