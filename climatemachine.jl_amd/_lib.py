@@ -20,6 +20,7 @@ OPT_STEP_GRAPH = 5
 OPT_STREAM_PRIORITY = 6
 OPT_TENDENCY_PAIRS = 7
 OPT_ASYNC_RUN = 8
+OPT_TENDENCY_FOUR_WAVES = 9
 CMDG_Q = dict(GRADFLUX_LIVE=1, LAW_NEEDS_GRADFLUX=2, NDERIVED=3, NUPDATED_AUX=4, FUSED_UPDATE_AUX=5,
               DIRECT_SEND=6, DIRECT_RECV=7, TENDENCY_ELEMS_PER_GROUP=8, HALO_PIPELINE=9, HOST_POST_NS=10, HOST_POST_COUNT=11, GRAPH_STEPS=12, TENDENCY_PAIRS=13,
               STATE_READ=16, AUX_READ=20)

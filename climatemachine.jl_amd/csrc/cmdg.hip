@@ -320,6 +320,7 @@ int EngineBase::init(const cmdg_desc *d)
     if (const char *v = getenv("CMDG_REFERENCE_HALO")) reference_halo = *v && *v != '0';
     if (const char *v = getenv("CMDG_HALO_PIPELINE")) no_pipeline = *v == '0';
     if (const char *v = getenv("CMDG_TENDENCY_PAIRS")) tendency_pairs = *v && *v != '0';
+    if (const char *v = getenv("CMDG_TENDENCY_FOUR_WAVES")) tendency_four_waves = *v && *v != '0';
     if (int r = build_pairs()) return r;
     if (int r = init_derived()) return r;
     HIPCHK(hipStreamSynchronize(s_comp));  // the fills of alloc0 have run
@@ -1873,6 +1874,11 @@ int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value)
         e->graph_failed = false;
         return CMDG_OK;
     case CMDG_OPT_STREAM_PRIORITY: return set_err(h, e->set_stream_priority(value));
+    case CMDG_OPT_TENDENCY_FOUR_WAVES:
+        if (int r = e->synchronize()) return set_err(h, r);
+        e->drop_graph();
+        e->tendency_four_waves = value != 0;
+        return CMDG_OK;
     case CMDG_OPT_ASYNC_RUN:
         if (value && !e->worker) {
             e->worker = new (std::nothrow) RunWorker();

@@ -165,6 +165,7 @@ struct EngineBase {
     // CMDG_OPT_TENDENCY_PAIRS: the tendency pass takes horizontally adjacent elements two to a
     // work-group and keeps the xi1 face they share on chip (TendencyShape<..., PAIR>, kernels.h);
     // the lists: (e0, e1) 1-based per work-group, e1 < 0 unrelated, 0 none
+    bool tendency_four_waves = false;  // CMDG_OPT_TENDENCY_FOUR_WAVES
     bool tendency_pairs = false;
     int64_t *d_pairs[2] = {nullptr, nullptr};  // interior, exterior
     int64_t npairs[2] = {0, 0};                // work-groups
@@ -570,6 +571,29 @@ struct EngineT : EngineBase {
                     else CMDG_TENDP(false, false);
                 }
 #undef CMDG_TENDP
+                prof_end(st);
+                return;
+            }
+        }
+        if constexpr (CMDG_TEND_FOUR_WAVES != 0 && KDims<NQ_, NQV_>::Np > 125 && node_cache_size<P>::value == 0 &&
+                      NQ_ == NQV_) {
+            if (tendency_four_waves) {  // CMDG_OPT_TENDENCY_FOUR_WAVES (k_tendency_big)
+                const dim3 bgrid((unsigned)n), bblock(256);
+#define CMDG_TENDB(L, G)                                                                                 \
+    do {                                                                                                 \
+        if (recv)                                                                                        \
+            hipLaunchKernelGGL((k_tendency_big<P, NQ_, NQV_, L, G, true>), bgrid, bblock, 0, st, args);  \
+        else                                                                                             \
+            hipLaunchKernelGGL((k_tendency_big<P, NQ_, NQV_, L, G, false>), bgrid, bblock, 0, st, args); \
+    } while (0)
+                if (c.lsrk) {
+                    if (gfl) CMDG_TENDB(true, true);
+                    else CMDG_TENDB(true, false);
+                } else {
+                    if (gfl) CMDG_TENDB(false, true);
+                    else CMDG_TENDB(false, false);
+                }
+#undef CMDG_TENDB
                 prof_end(st);
                 return;
             }

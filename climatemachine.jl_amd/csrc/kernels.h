@@ -48,6 +48,12 @@
 #ifndef CMDG_TEND_PAIRS
 #define CMDG_TEND_PAIRS 0
 #endif
+// four-wave work-groups for the tendency pass of large elements (k_tendency_big,
+// CMDG_OPT_TENDENCY_FOUR_WAVES): measured and rejected in round 4 (BOMEX k_tendency 596 -> 869 us,
+// profiles/r04_ab_tendency_four_waves.txt), kept buildable: make EXTRA=-DCMDG_TEND_FOUR_WAVES=1
+#ifndef CMDG_TEND_FOUR_WAVES
+#define CMDG_TEND_FOUR_WAVES 0
+#endif
 // tendency pass of large elements (N >= 5) in two launches, volume then interface + update
 // (see TendencyShape::SPLIT; off: measured slower than two elements per work-group), and the
 // register budgets asked for the two halves (waves per SIMD)
@@ -875,6 +881,271 @@ __global__ void __launch_bounds__((tendency_threads<P, NQ, NQV, TEND_FUSED, true
     k_tendency_pair_small(const PassArgs<P> a)
 {
     tendency_body<P, NQ, NQV, LSRK, USE_GF, RECV, TEND_FUSED, true, true>(a);
+}
+
+// ---------------------------------------------------------------------------------
+// Tendency pass of LARGE elements (Np > 125) on four-wave work-groups (round 4).  The fused
+// two-element shape above keeps ONE eleven-wave work-group on a CU (132 KB of LDS, 167 VGPRs):
+// its phases -- loads, 2 800 fp64 VALU instructions per wave, barrier, contraction, gathers, flux,
+// lift -- overlap with nobody's, and the kernel is bound by their latencies, not by bytes
+// (profiles/r04_bomex_n6_8192_pmc_sq.json, r04_ab_tendency_pairs.txt).  A second SIX-wave
+// work-group is resident only at <= 128 VGPRs (they are placed 2-1-2-1 over the SIMDs), which the
+// moist law's interface phase cannot meet.  FOUR-wave work-groups are placed 1-1-1-1: three share
+// a CU at <= 168 VGPRs if each takes <= 53 KB of LDS.  So: 256 threads per element, every thread
+// owns node tid and node tid + 256 (the second round is 87 nodes = two waves at N = 6), face tasks
+// likewise in two rounds; LDS holds the three contravariant fluxes only (49 KB) -- the state is
+// not staged (the minus side of the faces and the fused update read it again, L2-warm) and the
+// source is kept in registers.  Arithmetic and summation order are those of tendency_body.
+// Measured (BOMEX, N = 6): 869 us against 596 us for the shape above -- three independent work-groups
+// per CU do not make up for 204 B of scratch per thread, the state read three times instead of once
+// and second rounds that fill a quarter of the lanes.  Not compiled in by default (CMDG_TEND_FOUR_WAVES).
+template <class P, int NQ, int NQV, bool LSRK, bool USE_GF, bool RECV>
+__global__ void __launch_bounds__(256, 3) k_tendency_big(const PassArgs<P> a)
+{
+    using KD = KDims<NQ, NQV>;
+    static_assert(node_cache_size<P>::value == 0, "no node cache in the four-wave shape");
+    const double a_t = a.tptr ? *a.tptr : a.t;
+    constexpr int Np = KD::Np, NS = P::NS, NAUX = P::NAUX, NGF = P::NGF, NHYP = P::NHYP, NHG = 3 * P::NGL,
+                  NFA = P::NFAUX, NT = 256, RV = (Np + NT - 1) / NT, RF = (KD::NFT + NT - 1) / NT;
+    static_assert(RV <= 2 && RF <= 2, "two rounds at most");
+    constexpr bool use_gf = NGF > 0 && USE_GF;
+    __shared__ double sD[NQ * NQ + (NQV == NQ ? 0 : NQV * NQV)];
+    const double *const sDv = sD + (NQV == NQ ? 0 : NQ * NQ);
+    __shared__ double sF[3 * NS * Np];  // [d][s][ijk]; afterwards the accumulator sT[s][ijk]
+    double *const sT = sF;
+    const int tid = threadIdx.x;
+    const int64_t e = a.elems[xcd_remap(blockIdx.x, gridDim.x)] - 1;
+    if (tid < NQ * NQ) sD[tid] = a.g.D[tid];
+    if constexpr (NQV != NQ) {
+        if (tid < NQV * NQV) sD[NQ * NQ + tid] = a.g.Dv[tid];
+    }
+    const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
+    Vec<NS> S[RV];
+    double MI[RV];
+    // ---- phase 1: pointwise physics of the nodes of both rounds
+#pragma unroll
+    for (int r = 0; r < RV; ++r) {
+        const int node = tid + NT * r;
+        MI[r] = 0;
+        S[r].negzero();
+        if (node < Np) {
+            const double *vg = a.g.vgeo + (int64_t)Np * a.g.nvgeo * e + node;
+            const double M = vg[VM * Np];
+            MI[r] = vg[VMI * Np];
+            Vec<NS> lQ;
+            Vec<NAUX> laux;
+            Vec<NGF> lgf;
+            Vec<NHYP> lhyp;
+            load_state<NS, Np>(lQ, a.Q, node, e);
+            load_state<NAUX, Np>(laux, a.aux, node, e);
+#pragma unroll
+            for (int s = 0; s < NGF; ++s) lgf[s] = 0.0;
+            if (use_gf) load_state<NGF, Np>(lgf, a.gf, node, e);
+#pragma unroll
+            for (int s = 0; s < NHYP; ++s) lhyp[s] = a.hypgrad[node + (int64_t)Np * (s + (int64_t)NHG * e)];
+            Vec<3 * NS> F, F2;
+            F.negzero();
+            P::flux_first_order(a.prm, F, lQ, laux, a_t, a.model_dir);
+            F2.negzero();
+            P::flux_second_order(a.prm, F2, lQ, lgf, lhyp, laux, a_t);
+#pragma unroll
+            for (int q = 0; q < 3 * NS; ++q) F[q] += F2[q];
+            if (hz) {
+                const double x11 = vg[XI1X1 * Np], x12 = vg[XI1X2 * Np], x13 = vg[XI1X3 * Np];
+                const double x21 = vg[XI2X1 * Np], x22 = vg[XI2X2 * Np], x23 = vg[XI2X3 * Np];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const double F1 = F[3 * s], F2_ = F[3 * s + 1], F3 = F[3 * s + 2];
+                    sF[(0 * NS + s) * Np + node] = M * (x11 * F1 + x12 * F2_ + x13 * F3);
+                    sF[(1 * NS + s) * Np + node] = M * (x21 * F1 + x22 * F2_ + x23 * F3);
+                }
+            }
+            if (vt) {
+                const double x31 = vg[XI3X1 * Np], x32 = vg[XI3X2 * Np], x33 = vg[XI3X3 * Np];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const double F1 = F[3 * s], F2_ = F[3 * s + 1], F3 = F[3 * s + 2];
+                    sF[(2 * NS + s) * Np + node] = M * (x31 * F1 + x32 * F2_ + x33 * F3);
+                }
+            }
+            if constexpr (P::HAS_SOURCE) {
+                Vec<P::NDER> lder;
+                load_state<P::NDER, Np>(lder, a.derived, node, e);
+                P::source(a.prm, S[r], lQ, lgf, laux, lder, a_t, a.model_dir);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: contractions (reference order: horizontal part, then vertical with the source)
+    Vec<NS> Tv[RV];
+#pragma unroll
+    for (int r = 0; r < RV; ++r) {
+        const int node = tid + NT * r;
+        if (node < Np) {
+            const int i = node % NQ, j = (node / NQ) % NQ, k = node / (NQ * NQ);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                double T = 0.0;
+                const double Told = a.beta != 0 ? a.tendency[node + (int64_t)Np * (s + (int64_t)NS * e)] : 0.0;
+                if (hz) {
+                    double lt = 0.0;
+                    if (a.direction == DIR_HORIZONTAL && P::HAS_SOURCE) lt += S[r][s];
+#pragma unroll
+                    for (int n = 0; n < NQ; ++n) {
+                        lt += MI[r] * sD[n + NQ * i] * sF[(0 * NS + s) * Np + n + NQ * (j + NQ * k)];
+                        lt += MI[r] * sD[n + NQ * j] * sF[(1 * NS + s) * Np + i + NQ * (n + NQ * k)];
+                    }
+                    T = a.beta != 0 ? a.alpha * lt + a.beta * Told : a.alpha * lt;
+                }
+                if (vt) {
+                    double lt = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < NQV; ++kk) {
+                        lt += MI[r] * sDv[kk + NQV * k] * sF[(2 * NS + s) * Np + i + NQ * (j + NQ * kk)];
+                        if (kk == k && P::HAS_SOURCE) lt += S[r][s];
+                    }
+                    if (hz)
+                        T = a.alpha * lt + T;
+                    else
+                        T = a.beta != 0 ? a.alpha * lt + a.beta * Told : a.alpha * lt;
+                }
+                Tv[r][s] = T;
+            }
+        }
+    }
+    __syncthreads();  // every read of sF is done: it becomes the accumulator sT
+#pragma unroll
+    for (int r = 0; r < RV; ++r) {
+        const int node = tid + NT * r;
+        if (node < Np) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sT[s * Np + node] = Tv[r][s];
+        }
+    }
+    __syncthreads();
+    // ---- faces, one round of tasks at a time; a round's lifts are applied before the next round
+    // (pair by pair: opposite faces touch disjoint nodes, and every node still receives its pairs in
+    // the order 1-2, 3-4, 5-6 -- the second round holds tasks of the last face only)
+    static_assert(RF == 1 || (RF - 1) * NT >= 4 * KD::Nfph, "later rounds must hold tasks of faces 5, 6 only");
+#pragma unroll
+    for (int r = 0; r < RF; ++r) {
+        const int t = tid + NT * r;
+        Vec<NS> lift;
+        int vidM = 0, fpair = -1;
+        if (t < KD::NFT) {
+            int f, n;
+            KD::face_task(t, f, n);
+            if (f < 4 ? hz : vt) {
+                const int facedir = f < 4 ? DIR_HORIZONTAL : DIR_VERTICAL;
+                FacePt fp;
+                face_setup<NQ, NQV>(a.g, e, t, f, n, fp);
+                Vec<NS> QM, QPn, QPd, flux;
+                Vec<NAUX> auxM, auxPn, auxPd;
+                Vec<NGF> gfM, gfP;
+                Vec<NHYP> hypM, hypP;
+#pragma unroll
+                for (int s = 0; s < NAUX; ++s) auxM[s] = 0;
+                load_state<NS, Np>(QM, a.Q, fp.vidM, e);
+#pragma unroll
+                for (int s = 0; s < NFA; ++s)
+                    auxM[P::face_aux(s)] = a.aux[fp.vidM + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * e)];
+#pragma unroll
+                for (int s = 0; s < NGF; ++s) gfM[s] = gfP[s] = 0.0;
+                const int gslot = RECV ? ghost_slot<Np>(a.h, fp.eP, fp.vidP) : -1;
+                if (use_gf) {
+                    load_state<NGF, Np>(gfM, a.gf, fp.vidM, e);
+                    load_plus<NGF, Np, NGF>(gfP, a.gf, a.h.recvGF, gslot, fp.vidP, fp.eP);
+                }
+#pragma unroll
+                for (int s = 0; s < NHYP; ++s)
+                    hypM[s] = a.hypgrad[fp.vidM + (int64_t)Np * (s + (int64_t)NHG * e)];
+                load_plus<NS, Np, NS>(QPn, a.Q, a.h.recvQ, gslot, fp.vidP, fp.eP);
+#pragma unroll
+                for (int s = 0; s < NAUX; ++s) auxPn[s] = 0;
+#pragma unroll
+                for (int s = 0; s < NFA; ++s)
+                    auxPn[P::face_aux(s)] =
+                        a.aux[fp.vidP + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * fp.eP)];
+                load_plus<NHG, Np, NHYP>(hypP, a.hypgrad, a.h.recvHG, gslot, fp.vidP, fp.eP);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) QPd[s] = QPn[s];
+#pragma unroll
+                for (int s = 0; s < NAUX; ++s) auxPd[s] = auxPn[s];
+                flux.negzero();
+                if (fp.bctag == 0) {
+                    nf_first_order<P>(a.prm, a.nf_first, flux, fp.n, QM, auxM, QPn, auxPn, a_t, facedir, nullptr);
+                    Vec<3 * NS> FM, FP;
+                    FM.negzero();
+                    P::flux_second_order(a.prm, FM, QM, gfM, hypM, auxM, a_t);
+                    FP.negzero();
+                    P::flux_second_order(a.prm, FP, QPd, gfP, hypP, auxPd, a_t);
+                    const double nh0 = fp.n[0] / 2, nh1 = fp.n[1] / 2, nh2 = fp.n[2] / 2;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        flux[s] += (FM[3 * s] + FP[3 * s]) * nh0 + (FM[3 * s + 1] + FP[3 * s + 1]) * nh1 +
+                                   (FM[3 * s + 2] + FP[3 * s + 2]) * nh2;
+                } else {
+                    load_state<NAUX, Np>(auxM, a.aux, fp.vidM, e);
+#pragma unroll
+                    for (int s = 0; s < NAUX; ++s) auxPn[s] = auxPd[s] = auxM[s];
+                    Vec<NS> Q1;
+                    Vec<NAUX> aux1;
+                    Vec<NGF> gf1;
+                    for (int s = 0; s < NS; ++s) Q1[s] = 0;
+                    for (int s = 0; s < NAUX; ++s) aux1[s] = 0;
+                    for (int s = 0; s < NGF; ++s) gf1[s] = 0;
+                    if (f == 4) {
+                        load_state<NS, Np>(Q1, a.Q, n + NQ * NQ, e);
+                        load_state<NAUX, Np>(aux1, a.aux, n + NQ * NQ, e);
+                        if (use_gf) load_state<NGF, Np>(gf1, a.gf, n + NQ * NQ, e);
+                    }
+                    P::boundary_state(a.prm, BS_FIRST, fp.bctag, QPn, auxPn, fp.n, QM, auxM, a_t, Q1, aux1);
+                    nf_first_order<P>(a.prm, a.nf_first, flux, fp.n, QM, auxM, QPn, auxPn, a_t, facedir, nullptr);
+                    Vec<3 * NS> FP;
+                    FP.negzero();
+                    P::boundary_flux_second_order(a.prm, fp.bctag, FP, QPd, gfP, hypP, auxPd, fp.n, QM, gfM,
+                                                  hypM, auxM, a_t, Q1, gf1, aux1);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        flux[s] += FP[3 * s] * fp.n[0] + FP[3 * s + 1] * fp.n[1] + FP[3 * s + 2] * fp.n[2];
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) lift[s] = a.alpha * fp.vMI * fp.sM * flux[s];
+                vidM = fp.vidM;
+                fpair = f / 2;
+            }
+        }
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) {
+            if (fpair == pp) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) sT[s * Np + vidM] -= lift[s];
+            }
+            __syncthreads();
+        }
+    }
+    // ---- store, with the LSRK update fused in
+#pragma unroll
+    for (int r = 0; r < RV; ++r) {
+        const int node = tid + NT * r;
+        if (node < Np) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int64_t o = node + (int64_t)Np * (s + (int64_t)NS * e);
+                const double T = sT[s * Np + node];
+                if constexpr (LSRK) {
+                    a.Qout[o] = a.Q[o] + a.rkb_dt * T;
+                    a.tendency[o] = T * a.rka_next;
+                } else {
+                    a.tendency[o] = T;
+                }
+            }
+        }
+    }
+    if constexpr (LSRK)
+        send_nodes<NS, NS>(a.h, 0, e, tid, NT, [&](int s, int n) {
+            return a.Q[n + (int64_t)Np * (s + (int64_t)NS * e)] + a.rkb_dt * sT[s * Np + n];
+        });
 }
 
 // ---------------------------------------------------------------------------------

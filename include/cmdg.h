@@ -219,6 +219,11 @@ int cmdg_synchronize(cmdg_handle h);
  *   horizontally adjacent elements two to a work-group and reads the xi1 face they share out of
  *   LDS instead of gathering it (laws with one polynomial order and no node cache; the pairs are
  *   found from vmap+ at create: faces that meet node for node).  Results are bit-identical.
+ * CMDG_OPT_TENDENCY_FOUR_WAVES (environment CMDG_TENDENCY_FOUR_WAVES): elements above N = 4 -- the
+ *   tendency pass on 256-thread work-groups, two nodes per thread, three work-groups per CU
+ *   (k_tendency_big) instead of two elements per eleven-wave work-group.  Bit-identical; a
+ *   recorded experiment like CMDG_OPT_TENDENCY_PAIRS (slower; effective only in a library built
+ *   with -DCMDG_TEND_FOUR_WAVES=1 / -DCMDG_TEND_PAIRS=1, a no-op otherwise).
  * CMDG_OPT_ASYNC_RUN (default 0): cmdg_lsrk_run hands the run to a thread the handle owns and
  *   returns at once (the tableau is copied, Q and dQ must stay valid): the calling thread is not the
  *   one that spends ~1 ms per step of a partitioned run inside hipGraphLaunch or posting RCCL
@@ -234,7 +239,8 @@ int cmdg_synchronize(cmdg_handle h);
 enum {
     CMDG_OPT_KEEP_GRADFLUX = 1, CMDG_OPT_STACK_HEIGHT = 2, CMDG_OPT_REFERENCE_HALO = 3,
     CMDG_OPT_HALO_PIPELINE = 4, CMDG_OPT_STEP_GRAPH = 5, CMDG_OPT_STREAM_PRIORITY = 6,
-    CMDG_OPT_TENDENCY_PAIRS = 7, CMDG_OPT_ASYNC_RUN = 8
+    CMDG_OPT_TENDENCY_PAIRS = 7, CMDG_OPT_ASYNC_RUN = 8,
+    CMDG_OPT_TENDENCY_FOUR_WAVES = 9
 };
 int cmdg_set_option(cmdg_handle h, int32_t option, int32_t value);
 
