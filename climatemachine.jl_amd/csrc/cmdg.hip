@@ -319,6 +319,7 @@ int EngineBase::init(const cmdg_desc *d)
     // debugging overrides of the two exchange options (cmdg_set_option still has the last word)
     if (const char *v = getenv("CMDG_REFERENCE_HALO")) reference_halo = *v && *v != '0';
     if (const char *v = getenv("CMDG_HALO_PIPELINE")) no_pipeline = *v == '0';
+    if (const char *v = getenv("CMDG_FUSED_COLUMNS")) fused_columns = *v && *v != '0';
     if (const char *v = getenv("CMDG_TENDENCY_PAIRS")) tendency_pairs = *v && *v != '0';
     if (const char *v = getenv("CMDG_TENDENCY_FOUR_WAVES")) tendency_four_waves = *v && *v != '0';
     if (int r = build_pairs()) return r;
@@ -1425,6 +1426,26 @@ int EngineBase::run_pre_hooks(const RhsCtx &c)
 int EngineBase::flow_deviation(double *Q, int64_t h0, int64_t nh)
 {
     if (nh <= 0) return CMDG_OK;
+    if (fused_columns && NQ >= 2 && NQ <= 8 && NQV == NQ && g.nvgeo >= 16 && d_Imat) {
+        // integral and subtraction in one launch (columns.h k_flow_deviation)
+        prof_begin(CMDG_K_STACK_INTEGRAL, s_comp);
+#define CMDG_FD_CASE(N)                                                                                  \
+    case N: {                                                                                            \
+        constexpr int SPB = 256 / (N * N);                                                               \
+        hipLaunchKernelGGL((k_flow_deviation<N>), dim3((unsigned)((nh + SPB - 1) / SPB)), dim3(256), 0,  \
+                           s_comp, (const double *)Q, ns, hooks.flow_u_col, aux, naux, hooks.flow_ud_col, \
+                           g.vgeo, g.nvgeo, 15, (const double *)d_Imat, hooks.flow_H, hooks.nvertelem,   \
+                           h0, nh);                                                                      \
+    } break;
+        switch (NQ) {
+            CMDG_FD_CASE(2) CMDG_FD_CASE(3) CMDG_FD_CASE(4) CMDG_FD_CASE(5) CMDG_FD_CASE(6) CMDG_FD_CASE(7)
+            CMDG_FD_CASE(8)
+        default: break;
+        }
+#undef CMDG_FD_CASE
+        prof_end(s_comp);
+        return CMDG_OK;
+    }
     if (int r = integrate_velocity(Q, ns, hooks.flow_u_col, hooks.nvertelem, h0, nh)) return r;
     const int64_t n = nh * hooks.nvertelem * Np;
     hipLaunchKernelGGL(k_column_minus_top_over_H, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)),
@@ -1455,6 +1476,7 @@ int EngineBase::integrate_velocity(const double *X, int nstate, int col, int nve
 int EngineBase::run_gradient_hooks(const RhsCtx &c, int64_t e0, int64_t e1)
 {
     if (e1 <= e0) return CMDG_OK;
+    if (!hooks.ops_before_gradients && column_chain(c, e0, e1, true)) return CMDG_OK;
     const int64_t n = (e1 - e0) * Np;
     const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 65535);
     for (int i = 0; i < hooks.ncopy; ++i)
@@ -1465,10 +1487,109 @@ int EngineBase::run_gradient_hooks(const RhsCtx &c, int64_t e0, int64_t e1)
     return run_column_ops(c, e0, e1);
 }
 
+// The recorded composition copy -> upward integrals -> reverse integral -> surface value as ONE
+// launch (columns.h k_column_chain) when it has the shape the ocean models record: every copied
+// gradient-flux column is the integrand AND the destination of one upward integral, every
+// reverse integral runs in place on an upward integral's result, every surface value is taken from
+// an upward integral that is not reversed.  Anything else: false, and the caller issues the
+// operations one by one.
+bool EngineBase::column_chain(const RhsCtx &c, int64_t e0, int64_t e1, bool with_copies)
+{
+    if (!fused_columns || !hooks.has_integral || NQ < 2 || NQ > 8 || NQV != NQ || g.nvgeo < 16 || !d_Imat)
+        return false;
+    const cmdg_stack_integral_desc &d = hooks.integral;
+    const int nv = hooks.nvertelem;
+    if (d.nout < 1 || d.nout > 4 || !stacked || nv < 1) return false;
+    ChainArgs ch{};
+    StackArgs &a = ch.a;
+    a.Q = c.Qin;
+    a.aux = aux;
+    a.vgeo = g.vgeo;
+    a.Imat = d_Imat;
+    a.nstate = ns;
+    a.naux = naux;
+    a.nvgeo = g.nvgeo;
+    a.nvert = nv;
+    a.jcv = 15;
+    a.h0 = e0 / nv;
+    a.nhorz = (e1 - e0) / nv;
+    ch.gf = gf;
+    ch.ngf = ngf;
+    for (int s = 0; s < STACK_MAXOUT; ++s) ch.gf_col[s] = ch.rev_dst[s] = ch.surf_dst[s] = -1;
+    for (int s = 0; s < d.nout; ++s) {
+        a.is_state[s] = d.src_is_state[s];
+        a.src[s] = d.src_col[s];
+        a.dst[s] = d.dst_col[s];
+        a.scale[s] = d.scale[s];
+        if (d.src_is_state[s] && !c.Qin) return false;
+    }
+    if (with_copies)
+        for (int i = 0; i < hooks.ncopy; ++i) {
+            int hit = -1;
+            for (int s = 0; s < d.nout; ++s)
+                if (!d.src_is_state[s] && d.src_col[s] == hooks.copy_aux_col[i] &&
+                    d.dst_col[s] == hooks.copy_aux_col[i] && ch.gf_col[s] < 0)
+                    hit = s;
+            // the copied column must feed exactly that integral (nobody else reads the copy)
+            for (int s = 0; s < d.nout; ++s)
+                if (s != hit && !d.src_is_state[s] && d.src_col[s] == hooks.copy_aux_col[i]) hit = -1;
+            if (hit < 0) return false;
+            ch.gf_col[hit] = hooks.copy_gf_col[i];
+            ch.gf_scale[hit] = hooks.copy_scale[i];
+        }
+    if (hooks.has_reverse_integral) {
+        const cmdg_stack_integral_desc &r = hooks.reverse_integral;
+        for (int q = 0; q < r.nout; ++q) {
+            int hit = -1;
+            for (int s = 0; s < d.nout; ++s)
+                if (d.dst_col[s] == r.rsrc_col[q] && r.rdst_col[q] == r.rsrc_col[q] && ch.rev_dst[s] < 0) hit = s;
+            if (hit < 0) return false;
+            ch.rev_dst[hit] = r.rdst_col[q];
+        }
+    }
+    for (int i = 0; i < hooks.nsurf; ++i) {
+        int hit = -1;
+        for (int s = 0; s < d.nout; ++s)
+            if (d.dst_col[s] == hooks.surf_src_col[i] && ch.rev_dst[s] < 0 && ch.surf_dst[s] < 0) hit = s;
+        if (hit < 0) return false;
+        for (int s = 0; s < d.nout; ++s)  // the destination is nobody's integrand or result
+            if (hooks.surf_dst_col[i] == d.dst_col[s] || (!d.src_is_state[s] && hooks.surf_dst_col[i] == d.src_col[s]))
+                return false;
+        ch.surf_dst[hit] = hooks.surf_dst_col[i];
+    }
+    // (two upward integrals must not write one column, nor read what another one writes)
+    for (int s = 0; s < d.nout; ++s)
+        for (int q = 0; q < d.nout; ++q)
+            if (q != s && (d.dst_col[s] == d.dst_col[q] || (!d.src_is_state[q] && d.src_col[q] == d.dst_col[s])))
+                return false;
+    if (a.nhorz <= 0) return true;
+    prof_begin(CMDG_K_STACK_INTEGRAL, s_comp);
+#define CMDG_CHAIN_CASE(N)                                                                                   \
+    case N: {                                                                                                \
+        constexpr int SPB = 256 / (N * N);                                                                   \
+        const dim3 grid((unsigned)((a.nhorz + SPB - 1) / SPB)), block(256);                                  \
+        switch (d.nout) {                                                                                    \
+        case 1: hipLaunchKernelGGL((k_column_chain<N, 1>), grid, block, 0, s_comp, ch); break;               \
+        case 2: hipLaunchKernelGGL((k_column_chain<N, 2>), grid, block, 0, s_comp, ch); break;               \
+        case 3: hipLaunchKernelGGL((k_column_chain<N, 3>), grid, block, 0, s_comp, ch); break;               \
+        default: hipLaunchKernelGGL((k_column_chain<N, 4>), grid, block, 0, s_comp, ch); break;              \
+        }                                                                                                    \
+    } break;
+    switch (NQ) {
+        CMDG_CHAIN_CASE(2) CMDG_CHAIN_CASE(3) CMDG_CHAIN_CASE(4) CMDG_CHAIN_CASE(5) CMDG_CHAIN_CASE(6)
+        CMDG_CHAIN_CASE(7) CMDG_CHAIN_CASE(8)
+    default: break;
+    }
+#undef CMDG_CHAIN_CASE
+    prof_end(s_comp);
+    return true;
+}
+
 // upward integral, downward integral, surface value down the column: elements [e0, e1)
 int EngineBase::run_column_ops(const RhsCtx &c, int64_t e0, int64_t e1)
 {
     if (e1 <= e0) return CMDG_OK;
+    if (column_chain(c, e0, e1, false)) return CMDG_OK;
     const int64_t n = (e1 - e0) * Np;
     const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 65535);
     const int nv = hooks.nvertelem;

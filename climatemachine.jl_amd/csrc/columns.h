@@ -138,6 +138,191 @@ __global__ __launch_bounds__(256) void k_reverse_stack_integral(StackArgs a)
     }
 }
 
+// The column operators of a law's update_auxiliary_state_gradient! in ONE walk up and (where
+// something needs the top value) one walk down the stack -- copy of a gradient-flux column into
+// the integrand's column, upward integrals, `top - value` reverse integral, surface value through
+// the column (hydrostatic_boussinesq_model.jl:693-726: four launches in the recorded composition,
+// 107 us per evaluation on the 48 x 48 x 16 box; this one moves 7 column passes instead of 11).
+// Same arithmetic in the same order as k_scaled_column_copy + k_stack_integral +
+// k_reverse_stack_integral + k_surface_to_column, value for value.
+struct ChainArgs {
+    StackArgs a;                    // the upward integrals (is_state / src / scale / dst)
+    const double *gf;               // state_gradient_flux (NULL: no fused copy)
+    int ngf;
+    int gf_col[STACK_MAXOUT];       // >= 0: integrand s = gf_scale[s] * gf[:, gf_col[s]] (the copy into
+    double gf_scale[STACK_MAXOUT];  // aux column src[s] is skipped: the integral overwrites it)
+    int rev_dst[STACK_MAXOUT];      // >= 0: aux[:, rev_dst[s]] = top of output s - output s
+    int surf_dst[STACK_MAXOUT];     // >= 0: aux[:, surf_dst[s]] = top of output s, every node
+};
+
+template <int NQ, int NOUT>
+__global__ __launch_bounds__(256) void k_column_chain(ChainArgs c)
+{
+    const StackArgs &a = c.a;
+    constexpr int Nij = NQ * NQ, Np = Nij * NQ, SPB = 256 / Nij;
+    __shared__ double sI[NQ * NQ];
+    const int tid = threadIdx.x;
+    if (tid < NQ * NQ) sI[tid] = a.Imat[tid];
+    __syncthreads();
+    const int sl = tid / Nij, ij = tid % Nij;
+    const int64_t eh = a.h0 + (int64_t)blockIdx.x * SPB + sl;
+    if (sl >= SPB || eh >= a.h0 + a.nhorz) return;
+    double lint[NOUT][NQ], lker[NOUT][NQ], lnext[NOUT][NQ];
+#pragma unroll
+    for (int s = 0; s < NOUT; ++s)
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) lint[s][k] = 0;
+    auto load_kernel = [&](int ev, double (&out)[NOUT][NQ]) {
+        const int64_t e = ev + eh * a.nvert;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int ijk = ij + Nij * k;
+            const double Jc = a.vgeo[ijk + (int64_t)Np * (a.jcv + (int64_t)a.nvgeo * e)];
+#pragma unroll
+            for (int s = 0; s < NOUT; ++s) {
+                const double f =
+                    c.gf_col[s] >= 0
+                        ? c.gf_scale[s] * c.gf[ijk + (int64_t)Np * (c.gf_col[s] + (int64_t)c.ngf * e)]
+                        : (a.is_state[s] ? a.Q[ijk + (int64_t)Np * (a.src[s] + (int64_t)a.nstate * e)]
+                                         : a.aux[ijk + (int64_t)Np * (a.src[s] + (int64_t)a.naux * e)]);
+                out[s][k] = (a.scale[s] * f) * Jc;
+            }
+        }
+    };
+    load_kernel(0, lker);
+    for (int ev = 0; ev < a.nvert; ++ev) {
+        const int64_t e = ev + eh * a.nvert;
+        if (ev + 1 < a.nvert) load_kernel(ev + 1, lnext);
+#pragma unroll
+        for (int s = 0; s < NOUT; ++s)
+#pragma unroll
+            for (int k = 0; k < NQ; ++k)
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) lint[s][k] += sI[k + NQ * n] * lker[s][n];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int ijk = ij + Nij * k;
+#pragma unroll
+            for (int s = 0; s < NOUT; ++s) {
+                a.aux[ijk + (int64_t)Np * (a.dst[s] + (int64_t)a.naux * e)] = lint[s][k];
+                lint[s][k] = lint[s][NQ - 1];
+            }
+        }
+        if (ev + 1 < a.nvert) {
+#pragma unroll
+            for (int s = 0; s < NOUT; ++s)
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) lker[s][k] = lnext[s][k];
+        }
+    }
+    // ---- down again: whatever needs the value at the top of the stack (lint[s][*] now)
+    bool second = false;
+#pragma unroll
+    for (int s = 0; s < NOUT; ++s) second = second || c.rev_dst[s] >= 0 || c.surf_dst[s] >= 0;
+    if (!second) return;
+    double v[NOUT][NQ], vnext[NOUT][NQ];
+    auto load_values = [&](int ev, double (&out)[NOUT][NQ]) {  // (this thread's own stores of the walk up)
+        const int64_t e = ev + eh * a.nvert;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+#pragma unroll
+            for (int s = 0; s < NOUT; ++s)
+                out[s][k] = c.rev_dst[s] >= 0
+                                ? a.aux[ij + Nij * k + (int64_t)Np * (a.dst[s] + (int64_t)a.naux * e)]
+                                : 0.0;
+    };
+    load_values(0, v);
+    for (int ev = 0; ev < a.nvert; ++ev) {
+        const int64_t e = ev + eh * a.nvert;
+        if (ev + 1 < a.nvert) load_values(ev + 1, vnext);
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int ijk = ij + Nij * k;
+#pragma unroll
+            for (int s = 0; s < NOUT; ++s) {
+                if (c.rev_dst[s] >= 0)
+                    a.aux[ijk + (int64_t)Np * (c.rev_dst[s] + (int64_t)a.naux * e)] = lint[s][0] - v[s][k];
+                if (c.surf_dst[s] >= 0)
+                    a.aux[ijk + (int64_t)Np * (c.surf_dst[s] + (int64_t)a.naux * e)] = lint[s][0];
+            }
+        }
+        if (ev + 1 < a.nvert) {
+#pragma unroll
+            for (int s = 0; s < NOUT; ++s)
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) v[s][k] = vnext[s][k];
+        }
+    }
+}
+
+// compute_flow_deviation! (HydrostaticBoussinesqCoupling.jl:43-85) in one launch: the upward
+// integral of Q[:, ucol + c] (c = 0, 1; VerticalIntegralModel.jl:60-81, only its top value is
+// needed) and dst[:, dcol + c] = Q[:, ucol + c] - top / H.  Same arithmetic as k_stack_integral<NQ, 2>
+// followed by k_column_minus_top_over_H.
+template <int NQ>
+__global__ __launch_bounds__(256) void k_flow_deviation(const double *__restrict__ Q, int nstate, int ucol,
+                                                        double *__restrict__ dst, int ndst, int dcol,
+                                                        const double *__restrict__ vgeo, int nvgeo, int jcv,
+                                                        const double *__restrict__ Imat, double H, int nvert,
+                                                        int64_t h0, int64_t nhorz)
+{
+    constexpr int Nij = NQ * NQ, Np = Nij * NQ, SPB = 256 / Nij;
+    __shared__ double sI[NQ * NQ];
+    const int tid = threadIdx.x;
+    if (tid < NQ * NQ) sI[tid] = Imat[tid];
+    __syncthreads();
+    const int sl = tid / Nij, ij = tid % Nij;
+    const int64_t eh = h0 + (int64_t)blockIdx.x * SPB + sl;
+    if (sl >= SPB || eh >= h0 + nhorz) return;
+    double lint[2][NQ], lker[2][NQ], lnext[2][NQ];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) lint[s][k] = 0;
+    auto load_kernel = [&](int ev, double (&out)[2][NQ]) {
+        const int64_t e = ev + eh * nvert;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int ijk = ij + Nij * k;
+            const double Jc = vgeo[ijk + (int64_t)Np * (jcv + (int64_t)nvgeo * e)];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                out[s][k] = (1.0 * Q[ijk + (int64_t)Np * (ucol + s + (int64_t)nstate * e)]) * Jc;
+        }
+    };
+    load_kernel(0, lker);
+    for (int ev = 0; ev < nvert; ++ev) {
+        if (ev + 1 < nvert) load_kernel(ev + 1, lnext);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int k = 0; k < NQ; ++k)
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) lint[s][k] += sI[k + NQ * n] * lker[s][n];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) lint[s][k] = lint[s][NQ - 1];
+        if (ev + 1 < nvert) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) lker[s][k] = lnext[s][k];
+        }
+    }
+    for (int ev = 0; ev < nvert; ++ev) {
+        const int64_t e = ev + eh * nvert;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int ijk = ij + Nij * k;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                dst[ijk + (int64_t)Np * (dcol + s + (int64_t)ndst * e)] =
+                    Q[ijk + (int64_t)Np * (ucol + s + (int64_t)nstate * e)] - lint[s][0] / H;
+        }
+    }
+}
+
 // aux[:, dst, e] = scale * src[:, scol, e] for elements [e0, e1)
 static __global__ void k_scaled_column_copy(double *__restrict__ aux, int naux, int dst,
                                             const double *__restrict__ src, int nsrc, int scol,

@@ -405,6 +405,10 @@ struct EngineBase {
     double *d_flowint = nullptr;  // (Np, 2, nelem) column integral of the horizontal velocity
     double *d_preT = nullptr;     // tendency of the nested operator of the hooks (pre_rhs_handle)
     int run_column_ops(const RhsCtx &c, int64_t e0, int64_t e1);
+    // the column operators of a recorded composition in one launch (columns.h k_column_chain,
+    // k_flow_deviation); CMDG_FUSED_COLUMNS=0 issues them one by one as recorded (A/B, tests)
+    bool fused_columns = true;
+    bool column_chain(const RhsCtx &c, int64_t e0, int64_t e1, bool with_copies);
     int run_gradient_hooks(const RhsCtx &c, int64_t e0, int64_t e1);
     double *d_Imat = nullptr;
     double *d_Dv = nullptr;  // vertical derivative matrix when the vertical order differs

@@ -230,3 +230,40 @@ def test_ocean_gyre_long_reference_regression_on_the_gpu(cm, torch):
     for f in keep:
         f.close()
     dg.close()
+
+
+def test_fused_column_operators_equal_the_recorded_sequence(cm, torch, monkeypatch):
+    """The column operators of the recorded update_auxiliary_state_gradient! composition run as
+    one launch (columns.h k_column_chain: copy + upward integrals + reverse integral + surface
+    value) and the flow deviation as one (k_flow_deviation); CMDG_FUSED_COLUMNS=0 issues them one
+    by one.  Same arithmetic in the same order: state and every auxiliary column bit for bit,
+    for the uncoupled gyre and for the coupled box with its flow deviation."""
+    from helpers import split_explicit_setup
+    O = cm.ocean
+    for coupled in (False, True):
+        res = []
+        for fused in ("0", "1"):
+            monkeypatch.setenv("CMDG_FUSED_COLUMNS", fused)
+            if coupled:
+                law, grid, _, _ = split_explicit_setup(True, Nx=4, Ny=3, Nz=3)
+            else:
+                law, grid = ocean_gyre_setup()
+            dg = cm.dgmodel.DGModel(law, grid)
+            keep = O.install_hydrostatic_boussinesq_hooks(dg)
+            rng = np.random.default_rng(9)
+            Q0 = law.init_state_prognostic(grid, dg.state_auxiliary.cpu().numpy(), 0.0)
+            Q0[:, 0:2] += 0.05 * rng.standard_normal(Q0[:, 0:2].shape)
+            Q0[:, 3] += 0.1 * rng.standard_normal(Q0[:, 3].shape)
+            Q = _gpu(torch, Q0)
+            solver = cm.odesolvers.LSRK144NiegemannDiehlBusch(dg, Q, dt=60.0)
+            solver.dostep(Q, nsteps=3)
+            dg.synchronize()
+            res.append((Q.cpu().numpy().copy(), dg.state_auxiliary.cpu().numpy().copy()))
+            dg.set_rhs_hooks()
+            for f in keep:
+                f.close()
+            dg.close()
+        nr = grid.nreal
+        assert np.isfinite(res[0][0][:nr]).all()
+        assert np.array_equal(res[0][0][:nr], res[1][0][:nr])
+        assert np.array_equal(res[0][1][:nr], res[1][1][:nr])
