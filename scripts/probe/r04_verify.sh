@@ -2,7 +2,7 @@
 # failure with the fix and with the old fill, graph == eager on the strong rehearsal, GPU suite
 mkdir -p gpurun_out/r4d
 CMDG_HALO_PRIORITY=1 python scripts/probe/priority_order_diag.py > gpurun_out/r4d/diag_fixed.txt 2>&1; echo "fixed:"; grep worst gpurun_out/r4d/diag_fixed.txt
-CMDG_HALO_PRIORITY=1 CMDG_DBG_WORK_MEMSET=null python scripts/probe/priority_order_diag.py > gpurun_out/r4d/diag_legacy_memset.txt 2>&1; echo "legacy fill:"; grep worst gpurun_out/r4d/diag_legacy_memset.txt
+for st in torch system; do python scripts/probe/memset_null_stream_order.py $st 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4d/memset_probe_$st.txt; done
 python scripts/measure_halo_exposure.py --scaling strong --size 8 --steps 100 --step-graph 2> gpurun_out/r4d/exp_graph.err | tail -1 > gpurun_out/r4d/exposure_strong_graph.json
 python -c "
 import json
