@@ -319,7 +319,7 @@ int EngineBase::init(const cmdg_desc *d)
     // debugging overrides of the two exchange options (cmdg_set_option still has the last word)
     if (const char *v = getenv("CMDG_REFERENCE_HALO")) reference_halo = *v && *v != '0';
     if (const char *v = getenv("CMDG_HALO_PIPELINE")) no_pipeline = *v == '0';
-    if (const char *v = getenv("CMDG_FUSED_COLUMNS")) fused_columns = *v && *v != '0';
+    if (const char *v = getenv("CMDG_FUSED_COLUMNS")) fused_columns = atoi(v);
     if (const char *v = getenv("CMDG_TENDENCY_PAIRS")) tendency_pairs = *v && *v != '0';
     if (const char *v = getenv("CMDG_TENDENCY_FOUR_WAVES")) tendency_four_waves = *v && *v != '0';
     if (int r = build_pairs()) return r;
@@ -584,10 +584,11 @@ int EngineBase::set_stack_height(int nv)
     return build_pairs();
 }
 
-// CMDG_OPT_STREAM_PRIORITY: both streams of the handle at the highest (1) or the default (0)
-// priority.  For a handle whose launches are small and form a long dependent chain next to another
-// handle's bandwidth-bound launches -- the barotropic model of the split-explicit ocean -- the
-// dispatcher then takes its work-groups first whenever a slot frees up.
+// CMDG_OPT_STREAM_PRIORITY: both streams of the handle at the highest (1), the default (0) or the
+// lowest (-1) priority.  Two handles whose launches run side by side -- the two models of the
+// split-explicit ocean -- can say who yields: measured there, the barotropic model's small
+// launches are best run at the lowest priority (they hide behind the slow model's evaluation
+// anyway, and every slot they take slows the kernels on the critical path).
 int EngineBase::set_stream_priority(int level)
 {
     int lo = 0, hi = 0;
@@ -1372,9 +1373,10 @@ int EngineBase::run_pre_hooks_a(const RhsCtx &c, RhsCtx &cc)
 {
     if (hooks_orphaned)
         return fail(CMDG_ERR_INVALID, "hooks: the nested operator of this handle was destroyed; set new hooks");
-    for (int i = 0; i < hooks.npre; ++i)
-        if (int r = filter_apply(reinterpret_cast<const FilterObj *>(hooks.pre_filter[i]), c.Qin, ns))
-            return r;
+    if (!filter_pair(c.Qin))  // (two vertical filters on disjoint states: one launch)
+        for (int i = 0; i < hooks.npre; ++i)
+            if (int r = filter_apply(reinterpret_cast<const FilterObj *>(hooks.pre_filter[i]), c.Qin, ns))
+                return r;
     if (hooks.pre_rhs_handle) {
         // conti3d_dg(ct3d_dQ, Q, p, t; increment = false); A.w = dQ.theta  (OceanModel.jl:456-477)
         EngineBase *ch = hooks.pre_rhs_handle->eng;
@@ -1388,6 +1390,53 @@ int EngineBase::run_pre_hooks_a(const RhsCtx &c, RhsCtx &cc)
         cc.beta = 0.0;
     }
     return CMDG_OK;
+}
+
+// The two pre filters of the ocean models as one launch (filters.h k_apply_vfilter_pair) when they
+// are vertical spectral FilterIndices filters on disjoint states; false: apply them one by one.
+bool EngineBase::filter_pair(double *Q)
+{
+    if (fused_columns < 2 || hooks.npre != 2 || NQ < 2 || NQ > 8 || NQV != NQ || nreal <= 0) return false;
+    const FilterObj *f1 = reinterpret_cast<const FilterObj *>(hooks.pre_filter[0]);
+    const FilterObj *f2 = reinterpret_cast<const FilterObj *>(hooks.pre_filter[1]);
+    for (const FilterObj *f : {f1, f2})
+        if (f->kind != CMDG_FILTER_SPECTRAL || f->target != CMDG_TARGET_INDICES || f->direction != DIR_VERTICAL)
+            return false;
+    if (f1->nindices + f2->nindices > 8) return false;
+    for (int i = 0; i < f1->nindices; ++i) {
+        if (f1->indices[i] > ns) return false;
+        for (int j = 0; j < f2->nindices; ++j)
+            if (f2->indices[j] > ns || f1->indices[i] == f2->indices[j]) return false;
+    }
+    FilterArgs a{};
+    a.Q = Q;
+    a.aux = aux;
+    a.vgeo = g.vgeo;
+    a.Fh = f1->d_Fh;
+    a.Fv = f1->d_Fv;
+    a.nstate = ns;
+    a.naux = naux;
+    a.nvgeo = g.nvgeo;
+    a.nreal = nreal;
+    a.nfs = f1->nindices + f2->nindices;
+    for (int i = 0; i < f1->nindices; ++i) a.idx[i] = f1->indices[i];
+    for (int j = 0; j < f2->nindices; ++j) a.idx[f1->nindices + j] = f2->indices[j];
+    a.do_h = 0, a.do_v = 1;
+    prof_begin(CMDG_K_FILTER, s_comp);
+#define CMDG_FP_CASE(N)                                                                                    \
+    case N:                                                                                                \
+        hipLaunchKernelGGL((k_apply_vfilter_pair<N>), dim3((unsigned)nreal), dim3(FDims<N>::NT),           \
+                           sizeof(double) * 2 * a.nfs * FDims<N>::Np, s_comp, a, (const double *)f2->d_Fv, \
+                           f1->nindices);                                                                  \
+        break;
+    switch (NQ) {
+        CMDG_FP_CASE(2) CMDG_FP_CASE(3) CMDG_FP_CASE(4) CMDG_FP_CASE(5) CMDG_FP_CASE(6) CMDG_FP_CASE(7)
+        CMDG_FP_CASE(8)
+    default: break;
+    }
+#undef CMDG_FP_CASE
+    prof_end(s_comp);
+    return true;
 }
 
 int EngineBase::run_pre_hooks_b(const RhsCtx &c)

@@ -407,8 +407,11 @@ struct EngineBase {
     int run_column_ops(const RhsCtx &c, int64_t e0, int64_t e1);
     // the column operators of a recorded composition in one launch (columns.h k_column_chain,
     // k_flow_deviation); CMDG_FUSED_COLUMNS=0 issues them one by one as recorded (A/B, tests)
-    bool fused_columns = true;
+    // (levels, for A/B: 1 the hooks' column operators, 2 + the pair of pre filters; fusing the
+    // stepper's coupling kernels as well was measured slower, profiles/r04_ab_ocean_fused_columns.txt)
+    int fused_columns = 2;
     bool column_chain(const RhsCtx &c, int64_t e0, int64_t e1, bool with_copies);
+    bool filter_pair(double *Q);
     int run_gradient_hooks(const RhsCtx &c, int64_t e0, int64_t e1);
     double *d_Imat = nullptr;
     double *d_Dv = nullptr;  // vertical derivative matrix when the vertical order differs

@@ -186,6 +186,48 @@ __global__ __launch_bounds__(FDims<NQ>::NT) void k_apply_filter(FilterArgs a)
     }
 }
 
+// Two vertical spectral FilterIndices filters on disjoint states in ONE launch (the ocean models'
+// update_auxiliary_state!: cutoff filter on (u, v), exponential filter on theta,
+// hydrostatic_boussinesq_model.jl:654-680): a state's result depends on its own column and its own
+// filter matrix only, so the values are those of the two launches.  The first nfa filtered states
+// of a.idx take Fv, the rest Fv2.
+template <int NQ>
+__global__ __launch_bounds__(FDims<NQ>::NT) void k_apply_vfilter_pair(FilterArgs a, const double *__restrict__ Fv2,
+                                                                     int nfa)
+{
+    constexpr int Np = FDims<NQ>::Np, NT = FDims<NQ>::NT;
+    extern __shared__ double lds[];
+    __shared__ double sFa[NQ * NQ], sFb[NQ * NQ];
+    const int tid = threadIdx.x;
+    const int64_t e = xcd_remap(blockIdx.x, gridDim.x);
+    const int nfs = a.nfs;
+    double *cur = lds, *nxt = lds + nfs * Np;
+    if (tid < NQ * NQ) {
+        sFa[tid] = a.Fv[tid];
+        sFb[tid] = Fv2[tid];
+    }
+    double *Qe = a.Q + (int64_t)Np * a.nstate * e;
+    for (int w = tid; w < nfs * Np; w += NT) {
+        const int fs = w / Np, ijk = w - fs * Np;
+        cur[w] = Qe[ijk + Np * (a.idx[fs] - 1)];
+    }
+    __syncthreads();
+    for (int w = tid; w < nfs * Np; w += NT) {  // filter_pass<NQ, 2> with the state's own matrix
+        const int ijk = w % Np, kq = ijk / (NQ * NQ);
+        const double *sF = w / Np < nfa ? sFa : sFb;
+        const double *col = cur + (w - kq * NQ * NQ);
+        double acc = 0.0;
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) acc += sF[kq + NQ * n] * col[n * NQ * NQ];
+        nxt[w] = acc;
+    }
+    __syncthreads();
+    for (int w = tid; w < nfs * Np; w += NT) {
+        const int fs = w / Np, ijk = w - fs * Np;
+        Qe[ijk + Np * (a.idx[fs] - 1)] = nxt[w];
+    }
+}
+
 // the reference's shared-memory tree (Filters.jl:848-861, 1047-1060): for n = 11..1, if
 // nreduce >= 2^n, entry ijk (1-based) adds entry ijk + 2^(n-1) when that partner exists
 template <int COUNT>

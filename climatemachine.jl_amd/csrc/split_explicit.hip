@@ -71,9 +71,9 @@ int initialize_states(EngineBase *s, const cmdg_ocean_coupling_desc *d)
 
 int slow_to_fast(EngineBase *s, EngineBase *f, const cmdg_ocean_coupling_desc *d, const double *dQ)
 {
-    if (int r = s->integrate_velocity(dQ, s->ns, d->slow_u_col, d->nvertelem)) return r;
     const int Nij = s->NQ * s->NQ, nv = d->nvertelem, Nqk2 = f->Np / Nij;
     const int64_t nh = s->nreal / nv;
+    if (int r = s->integrate_velocity(dQ, s->ns, d->slow_u_col, d->nvertelem)) return r;
     if (int r = order(s, f->s_comp, s->s_comp)) return r;
     hipLaunchKernelGGL(k_top_to_layer, dim3(nblocks(nh * f->Np)), dim3(256), 0, s->s_comp, f->aux,
                        f->naux, d->fast_GU_col, (const double *)s->d_flowint, Nij, s->NQ, nv, Nqk2, nh);

@@ -242,7 +242,7 @@ def test_fused_column_operators_equal_the_recorded_sequence(cm, torch, monkeypat
     O = cm.ocean
     for coupled in (False, True):
         res = []
-        for fused in ("0", "1"):
+        for fused in ("0", "2"):
             monkeypatch.setenv("CMDG_FUSED_COLUMNS", fused)
             if coupled:
                 law, grid, _, _ = split_explicit_setup(True, Nx=4, Ny=3, Nz=3)

@@ -381,3 +381,4 @@ def test_split_explicit_through_rccl_equals_device_copies(cm, torch):
         assert torch.isfinite(out[-1][0]).all() and torch.isfinite(out[-1][1]).all()
         _close(dg3, dg2, keep)
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
