@@ -7,11 +7,11 @@ need torch (device memory) and ``libcmdg.so`` (the hand-written HIP kernels); th
 are imported lazily so that the host-side pieces work without a GPU."""
 from . import atmos, balancelaws, mesh, moist, ocean, ocean01  # noqa: F401
 
-__all__ = ["mesh", "balancelaws", "atmos", "moist", "ocean", "ocean01", "dgmodel", "odesolvers"]
+__all__ = ["mesh", "balancelaws", "atmos", "moist", "ocean", "ocean01", "dgmodel", "odesolvers", "plugins"]
 
 
 def __getattr__(name):
-    if name in ("dgmodel", "odesolvers", "_lib"):
+    if name in ("dgmodel", "odesolvers", "_lib", "plugins"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

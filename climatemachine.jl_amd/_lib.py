@@ -144,6 +144,7 @@ SYMBOLS = [
      [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i32, _vp, _vp, _vp]),
     ("cmdg_group_split_explicit01_step", C.c_int,
      [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i32, _vp, _vp, _vp]),
+    ("cmdg_load_plugin", C.c_int, [C.c_char_p]),
     ("cmdg_lsrk_update", C.c_int, [_vp, _vp, _vp, _d, _d]),
     ("cmdg_ls3n_step", C.c_int, [_vp, _vp, _vp, _vp, _d, _d, _i32, _vp, _vp, _vp]),
     ("cmdg_ssprk_step", C.c_int, [_vp, _vp, _vp, _vp, _d, _d, _i32, _vp, _vp, _vp]),

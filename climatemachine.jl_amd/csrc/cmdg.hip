@@ -1816,6 +1816,63 @@ using namespace cmdg;
 
 static thread_local std::string g_create_err;
 
+// ---- engine plug-ins: balance-law functors / template combinations outside the compiled set ----
+// A plug-in is a shared object built from this library's own headers (csrc/engine.h + a
+// physics_*.h, one translation unit instantiating make_engine<Law, Nq>) that exports
+//   cmdg::EngineBase *cmdg_plugin_make_engine(const cmdg_desc *, char *err, int errlen)
+// returning NULL for a descriptor it does not serve.  climatemachine.jl_amd/plugins.py writes and
+// builds them with hipcc (the reference compiles a law's pointwise functions into its kernels when
+// the model is first run; this is the ahead-of-time equivalent for a C ABI).
+namespace {
+typedef EngineBase *(*plugin_make_t)(const cmdg_desc *, char *, int);
+std::vector<plugin_make_t> g_plugin_make;
+std::vector<std::string> g_plugin_path;
+bool g_plugins_env_read = false;
+int load_plugin(const char *path, std::string &err)
+{
+    for (const auto &p : g_plugin_path)
+        if (p == path) return CMDG_OK;
+    void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) {
+        err = std::string("cannot load plug-in: ") + dlerror();
+        return CMDG_ERR_INVALID;
+    }
+    plugin_make_t f = (plugin_make_t)dlsym(lib, "cmdg_plugin_make_engine");
+    if (!f) {
+        err = std::string(path) + " does not export cmdg_plugin_make_engine";
+        dlclose(lib);
+        return CMDG_ERR_INVALID;
+    }
+    g_plugin_make.push_back(f);
+    g_plugin_path.push_back(path);
+    return CMDG_OK;
+}
+EngineBase *plugin_engine(const cmdg_desc *d, std::string &err)
+{
+    if (!g_plugins_env_read) {
+        g_plugins_env_read = true;
+        if (const char *env = getenv("CMDG_PLUGINS")) {
+            std::string all(env), e2;
+            size_t a = 0;
+            while (a <= all.size()) {
+                const size_t b = all.find(':', a);
+                const std::string one = all.substr(a, b == std::string::npos ? std::string::npos : b - a);
+                if (!one.empty() && load_plugin(one.c_str(), e2) != CMDG_OK) err += e2 + "; ";
+                if (b == std::string::npos) break;
+                a = b + 1;
+            }
+        }
+    }
+    for (plugin_make_t f : g_plugin_make) {
+        char buf[512] = {0};
+        if (EngineBase *e = f(d, buf, (int)sizeof(buf))) return e;
+        if (buf[0]) err += std::string(buf) + "; ";
+    }
+    if (g_plugin_make.empty() && err.empty()) err = "none loaded";
+    return nullptr;
+}
+}  // namespace
+
 static int set_err(cmdg_handle h, int code)
 {
     if (h && h->eng && code != CMDG_OK) h->err = h->eng->err;
@@ -1825,6 +1882,15 @@ static int set_err(cmdg_handle h, int code)
 extern "C" {
 
 const char *cmdg_version(void) { return "cmdg 0.1 (gfx950)"; }
+
+int cmdg_load_plugin(const char *path)
+{
+    if (!path) return CMDG_ERR_INVALID;
+    std::string err;
+    const int r = load_plugin(path, err);
+    if (r) g_create_err = err;
+    return r;
+}
 
 const char *cmdg_status_string(int status)
 {
@@ -1895,9 +1961,13 @@ int cmdg_create(const cmdg_desc *d, cmdg_handle *out)
     case CMDG_PHYSICS_BAROTROPIC_SE01: e = make_engine_se01(d, err); break;
     default: err = "unknown physics_id"; break;
     }
-    if (!e) {
-        g_create_err = err;
-        return CMDG_ERR_UNSUPPORTED;
+    if (!e) {  // not compiled in: ask the plug-ins (cmdg_load_plugin / CMDG_PLUGINS)
+        std::string perr;
+        e = plugin_engine(d, perr);
+        if (!e) {
+            g_create_err = perr.empty() ? err : err + "; plug-ins: " + perr;
+            return CMDG_ERR_UNSUPPORTED;
+        }
     }
     int r = e->init(d);
     if (r != CMDG_OK) {

@@ -141,6 +141,20 @@ int cmdg_physics_counts(int32_t physics_id, const int32_t *iparam, int32_t out[6
  * add 8 B per node of vmapsend and 4 B per ghost node. */
 int cmdg_create(const cmdg_desc *desc, cmdg_handle *out);
 int cmdg_destroy(cmdg_handle h);
+
+/* Balance laws / template combinations outside the compiled set.  In the reference a law's
+ * pointwise functions are compiled into the kernels when the model first runs
+ * (src/BalanceLaws/interface.jl:37-464, KernelAbstractions); behind a C ABI the equivalent is a
+ * plug-in: a shared object built from this library's own kernel headers (csrc/engine.h + a
+ * physics_*.h device functor, one translation unit instantiating make_engine<Law, Nq>) that exports
+ *   cmdg::EngineBase *cmdg_plugin_make_engine(const cmdg_desc *, char *err, int errlen)
+ * and returns NULL for descriptors it does not serve.  cmdg_create asks the loaded plug-ins when no
+ * compiled-in engine takes a descriptor (a law the library knows in a combination or at an order
+ * it was not built for, or a physics_id of the plug-in's own).  cmdg_load_plugin loads one
+ * (idempotent; CMDG_ERR_INVALID with the reason in cmdg_last_error(NULL)); the environment variable
+ * CMDG_PLUGINS (colon-separated paths) is read at the first create that needs it.
+ * climatemachine.jl_amd/plugins.py writes and builds plug-ins with hipcc. */
+int cmdg_load_plugin(const char *path);
 /* message of the last failure on this handle (never NULL) */
 const char *cmdg_last_error(cmdg_handle h);
 

@@ -82,3 +82,22 @@ def test_rhs_hooks_struct_matches_header_field_order():
     assert fields == [f[0] for f in cm._lib.CmdgRhsHooks._fields_], fields
     txt = open(os.path.join(ROOT, "include", "cmdg.h")).read()
     assert "#define CMDG_MAX_HOOK_OPS %d" % cm._lib.MAX_HOOK_OPS in txt
+
+
+def test_engine_plugin_builds_and_loads():
+    """climatemachine.jl_amd/plugins.py writes a plug-in translation unit, hipcc cross-compiles it
+    for gfx950 against libcmdg.so, it exports cmdg_plugin_make_engine and cmdg_load_plugin takes
+    it; something that is not a plug-in is refused with the reason.  (Its engine runs on the GPU:
+    tests/test_gpu_plugins.py.)"""
+    import ctypes as C
+    import subprocess
+    from cmdg_loader import cm
+    so = cm.plugins.build_dry_atmos(orient=True, ref_state=False, hyperdiffusion=True, N=4)
+    names = subprocess.check_output(["nm", "-D", so]).decode()
+    assert " T cmdg_plugin_make_engine" in names
+    L = cm._lib.lib()
+    assert L.cmdg_load_plugin(so.encode()) == 0
+    assert L.cmdg_load_plugin(so.encode()) == 0          # idempotent
+    L.cmdg_last_error.restype = C.c_char_p
+    assert L.cmdg_load_plugin(b"/nonexistent/plugin.so") != 0
+    assert b"cannot load plug-in" in L.cmdg_last_error(None)
