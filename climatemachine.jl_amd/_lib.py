@@ -115,6 +115,8 @@ SYMBOLS = [
     ("cmdg_synchronize", C.c_int, [_vp]),
     ("cmdg_set_option", C.c_int, [_vp, _i32, _i32]),
     ("cmdg_query", C.c_int, [_vp, _i32, _vp]),
+    ("cmdg_export_hypervisc_grad", C.c_int, [_vp, _vp]),
+    ("cmdg_export_gradient_flux", C.c_int, [_vp, _vp]),
     ("cmdg_halo_begin", C.c_int, [_vp, _vp, _i32]),
     ("cmdg_halo_end", C.c_int, [_vp, _vp, _i32]),
     ("cmdg_fillsendbuf", C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32]),

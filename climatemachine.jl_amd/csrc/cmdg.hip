@@ -129,6 +129,7 @@ EngineBase::~EngineBase()
         if (s.ev_pulled) hipEventDestroy(s.ev_pulled);
     }
     if (own_gf && gf) hipFree(gf);
+    if (gf_scratch) hipFree(gf_scratch);
     if (own_hg && hypgrad) hipFree(hypgrad);
     if (own_hd && hypdiv) hipFree(hypdiv);
     if (W[0]) hipFree(W[0]);
@@ -288,12 +289,16 @@ int EngineBase::init(const cmdg_desc *d)
         HIPCHK(hipMemsetAsync(*p, 0, sizeof(double) * n, s_comp));
         return CMDG_OK;
     };
-    gf = d->state_gradient_flux;
+    gf = gf_node_major() ? nullptr : d->state_gradient_flux;
+    gf_user = gf_node_major() ? d->state_gradient_flux : nullptr;
     if (!gf) {
         own_gf = true;
         if (int r = alloc0(&gf, nd * ngf)) return r;
     }
-    hypgrad = d->Qhypervisc_grad;
+    // Qhypervisc_grad is node-major inside the library (cmdg_common.h); a caller's array receives
+    // the reference layout after every evaluation (export_hypgrad)
+    hypgrad = CMDG_HG_NODE_MAJOR ? nullptr : d->Qhypervisc_grad;
+    hypgrad_user = CMDG_HG_NODE_MAJOR && ngl > 0 ? d->Qhypervisc_grad : nullptr;
     if (!hypgrad) {
         own_hg = true;
         if (int r = alloc0(&hypgrad, nd * 3 * ngl)) return r;
@@ -438,6 +443,37 @@ void EngineBase::prof_end(hipStream_t st)
     if (!profiling) return;
     hipEventRecord(prof.back().e1, st);
 }
+// the library's Qhypervisc_grad / state_gradient_flux in the reference layout (Np, ncol, nelem), on demand
+int EngineBase::export_hypgrad(double *dst)
+{
+    if (!dst) dst = hypgrad_user;
+    if (ngl == 0) return CMDG_OK;
+    if (!dst) return fail(CMDG_ERR_INVALID, "cmdg_export_hypervisc_grad: no destination (cmdg_desc.Qhypervisc_grad was NULL)");
+    const int64_t n = (int64_t)Np * 3 * ngl * nelem;
+    if (CMDG_HG_NODE_MAJOR) {
+        hipLaunchKernelGGL(k_export_node_major, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s_comp, dst, hypgrad,
+                           Np, 3 * ngl, nelem);
+    } else if (dst != hypgrad) {
+        HIPCHK(hipMemcpyAsync(dst, hypgrad, sizeof(double) * n, hipMemcpyDeviceToDevice, s_comp));
+    }
+    HIPCHK(hipStreamSynchronize(s_comp));
+    return CMDG_OK;
+}
+int EngineBase::export_gradflux(double *dst)
+{
+    if (!dst) dst = gf_node_major() ? gf_user : gf;
+    if (ngf == 0) return CMDG_OK;
+    if (!dst) return fail(CMDG_ERR_INVALID, "cmdg_export_gradient_flux: no destination (cmdg_desc.state_gradient_flux was NULL)");
+    const int64_t n = (int64_t)Np * ngf * nelem;
+    if (gf_node_major()) {
+        hipLaunchKernelGGL(k_export_node_major, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s_comp, dst, gf, Np,
+                           ngf, nelem);
+    } else if (dst != gf) {
+        HIPCHK(hipMemcpyAsync(dst, gf, sizeof(double) * n, hipMemcpyDeviceToDevice, s_comp));
+    }
+    HIPCHK(hipStreamSynchronize(s_comp));
+    return CMDG_OK;
+}
 void EngineBase::prof_collect()
 {
     for (auto &r : prof) {
@@ -497,7 +533,8 @@ int EngineBase::halo_pack(int s, double *array, int nvar, int ncol, bool on_halo
         const int64_t n = nvmapsend * nvar;
         prof_begin(CMDG_K_PACK, s_comm);
         hipLaunchKernelGGL(k_fillsendbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s_comm,
-                           h.sendbuf, array, d_vmapsend, nvmapsend, Np, nvar, ncol);
+                           h.sendbuf, array, d_vmapsend, nvmapsend, Np, nvar, ncol,
+                           (int)node_major(array));
         prof_end(s_comm);
     }
     if (!capturing) HIPCHK(ev_record(h.ev_packed, s_comm));  // (read by the local transport only)
@@ -718,7 +755,8 @@ int EngineBase::halo_end(int s, double *array, int nvar, bool unpack, bool on_ha
         const int64_t n = nvmaprecv * nvar;
         prof_begin(CMDG_K_UNPACK, s_comm);
         hipLaunchKernelGGL(k_transferrecvbuf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           s_comm, array, h.recvbuf, d_vmaprecv, nvmaprecv, Np, nvar, h.ncol);
+                           s_comm, array, h.recvbuf, d_vmaprecv, nvmaprecv, Np, nvar, h.ncol,
+                           (int)node_major(array));
         prof_end(s_comm);
     }
     if (on_halo_stream) return CMDG_OK;  // the consumer is the next launch of the halo stream
@@ -842,7 +880,18 @@ int EngineBase::rhs_segment(int seg, const RhsCtx &c)
         TRY(exterior_end());
         if (dsend && gfl && !gradient_filter) mark_fresh(SLOT_GF, gf, ngf);
         if (dsend && hyper) mark_fresh(SLOT_HG, hypgrad, 3 * ngl);
-        if (gradient_filter && gfl) TRY(filter_apply(gradient_filter, gf, ngf));  // (:185-193)
+        if (gradient_filter && gfl) {  // (:185-193)
+            if (gf_node_major()) {  // the filter kernels work on the reference layout
+                const int64_t n = (int64_t)Np * ngf * nelem;
+                const unsigned nb = (unsigned)((n + 255) / 256);
+                if (!gf_scratch) HIPCHK(hipMalloc(&gf_scratch, sizeof(double) * n));
+                hipLaunchKernelGGL(k_export_node_major, dim3(nb), dim3(256), 0, s_comp, gf_scratch, gf, Np, ngf, nelem);
+                TRY(filter_apply(gradient_filter, gf_scratch, ngf));
+                hipLaunchKernelGGL(k_import_node_major, dim3(nb), dim3(256), 0, s_comp, gf, gf_scratch, Np, ngf, nelem);
+            } else {
+                TRY(filter_apply(gradient_filter, gf, ngf));
+            }
+        }
         if (comm) {  // both begin here: packed back to back, posted in one group
             int slots[2], ns_ = 0;
             if (gfl) {
@@ -1318,6 +1367,9 @@ int EngineBase::set_hooks(const cmdg_rhs_hooks *hk)
     if (hk->npre < 0 || hk->npre > CMDG_MAX_HOOK_OPS || hk->ncopy < 0 || hk->ncopy > CMDG_MAX_HOOK_OPS ||
         hk->nsurf < 0 || hk->nsurf > CMDG_MAX_HOOK_OPS)
         return fail(CMDG_ERR_INVALID, "hooks: too many operations");
+    if (gf_node_major() && hk->ncopy > 0)
+        return fail(CMDG_ERR_UNSUPPORTED, "hooks: gradient-flux copies are not built for laws whose state_gradient_flux "
+                                          "is node-major inside the library (the dry atmosphere)");
     const bool cols = hk->has_integral || hk->has_reverse_integral || hk->nsurf > 0 ||
                       hk->has_flow_deviation;
     if (cols && (!stacked || hk->nvertelem < 1 || nreal % hk->nvertelem || nghost % hk->nvertelem))
@@ -2175,6 +2227,20 @@ int cmdg_query(cmdg_handle h, int32_t what, int64_t *out)
         }
         return set_err(h, h->eng->fail(CMDG_ERR_INVALID, "cmdg_query: unknown item"));
     }
+}
+
+int cmdg_export_hypervisc_grad(cmdg_handle h, double *dst)
+{
+    if (!h) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
+    return set_err(h, h->eng->export_hypgrad(dst));
+}
+
+int cmdg_export_gradient_flux(cmdg_handle h, double *dst)
+{
+    if (!h) return CMDG_ERR_INVALID;
+    DevGuard guard_(h->eng);
+    return set_err(h, h->eng->export_gradflux(dst));
 }
 
 int cmdg_halo_begin(cmdg_handle h, double *array, int32_t nstate)

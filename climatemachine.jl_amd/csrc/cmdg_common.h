@@ -147,6 +147,51 @@ __device__ __forceinline__ void load_plus(Vec<NLOAD> &dst, const double *__restr
         for (int s = 0; s < NLOAD; ++s) dst[s] = arr[vidP + (int64_t)Np * (s + (int64_t)NVAR * eP)];
     }
 }
+// Qhypervisc_grad inside the library (round 4): node-major within an element, (NHG, Np, nelem)
+// instead of the reference's (Np, NHG, nelem).  A plus-side gather of a face node then reads NHG * 8
+// contiguous bytes instead of NHG values at a stride of Np * 8: on a xi1 / xi2 face of an N = 4
+// element the column-major form touches every 128-byte line of all NHG columns of the neighbour
+// (5 x the bytes used), the node-major form 1.3-2.3 x.  The volume reads are one contiguous
+// record per thread, the stores go out of LDS in memory order.  A caller that hands
+// Qhypervisc_grad to cmdg_create gets the reference layout copied out after every evaluation
+// (k_export_hg); CMDG_HG_NODE_MAJOR=0 builds the reference layout in place (the A/B).
+#ifndef CMDG_HG_NODE_MAJOR
+#define CMDG_HG_NODE_MAJOR 1
+#endif
+template <bool NODE_MAJOR, int NCOL, int Np>
+__device__ __forceinline__ int64_t col_at(int n, int s, int64_t e)
+{
+    return NODE_MAJOR ? s + (int64_t)NCOL * (n + (int64_t)Np * e) : n + (int64_t)Np * (s + (int64_t)NCOL * e);
+}
+template <int NHG, int Np>
+__device__ __forceinline__ int64_t hg_at(int n, int s, int64_t e)
+{
+    return col_at<CMDG_HG_NODE_MAJOR != 0, NHG, Np>(n, s, e);
+}
+template <int NHG, int Np, int NLOAD>
+__device__ __forceinline__ void load_plus_hg(Vec<NLOAD> &dst, const double *__restrict__ arr,
+                                             const double *__restrict__ recv, int gslot, int vidP, int64_t eP)
+{
+    if (gslot >= 0) {
+#pragma unroll
+        for (int s = 0; s < NLOAD; ++s) dst[s] = recv[s + (int64_t)NHG * gslot];
+    } else {
+#pragma unroll
+        for (int s = 0; s < NLOAD; ++s) dst[s] = arr[hg_at<NHG, Np>(vidP, s, eP)];
+    }
+}
+// the first NW of the NHG columns of element e of a node-major array out of LDS (src[s * Np + n])
+// in memory order
+template <int NHG, int Np, int NW>
+__device__ __forceinline__ void store_node_major(double *__restrict__ arr, int64_t e, int tid, int nthreads,
+                                                 const double *src)
+{
+    double *dst = arr + (int64_t)NHG * Np * e;
+    for (int m = tid; m < NHG * Np; m += nthreads) {
+        const int n = m / NHG, s = m - n * NHG;
+        if (NW == NHG || s < NW) dst[m] = src[s * Np + n];
+    }
+}
 // exterior launches: the element's nodes of vmapsend into send buffer `which` (NVAR columns per
 // position, the first NW written); value(s, node) is the value the pass stores for the node
 template <int NVAR, int NW, class F>

@@ -184,6 +184,13 @@ struct EngineBase {
     double *aux = nullptr, *gf = nullptr, *hypgrad = nullptr, *hypdiv = nullptr;
     double *derived = nullptr;  // (Np, NDER, nelem), library-owned
     bool own_gf = false, own_hg = false, own_hd = false;
+    // the caller's Qhypervisc_grad / state_gradient_flux (reference layout) when the working copy is
+    // node-major: written by cmdg_export_* only; gf_scratch: reference-layout copy for a gradient filter
+    double *hypgrad_user = nullptr, *gf_user = nullptr, *gf_scratch = nullptr;
+    bool node_major(const double *array) const
+    {
+        return (CMDG_HG_NODE_MAJOR && array == hypgrad) || (array == gf && gf_node_major());
+    }
     // ---- runtime -----------------------------------------------------------------------
     int dev = 0;  // the device this engine was created on (every ABI entry binds to it)
     hipStream_t s_comp = nullptr, s_comm = nullptr;
@@ -222,6 +229,7 @@ struct EngineBase {
     virtual void launch_update_aux(const RhsCtx &c, int64_t e0, int64_t e1) = 0;
     virtual bool has_update_aux() const = 0;
     virtual bool law_needs_gradflux() const = 0;
+    virtual bool gf_node_major() const = 0;  // state_gradient_flux kept (ngf, Np, nelem) inside the library
     bool keep_gradflux = false;  // CMDG_OPT_KEEP_GRADFLUX
     // is state_gradient_flux formed (and exchanged) by an evaluation?
     bool gf_live() const
@@ -371,6 +379,8 @@ struct EngineBase {
     // (nvar columns per packed position = the leading columns of the ncol-column array; ncol = 0:
     // the whole array, nvar == ncol, as the reference packs)
     // on_halo_stream (pipelined()): producer and consumer are launches of the halo stream itself
+    int export_hypgrad(double *dst);
+    int export_gradflux(double *dst);
     int halo_begin(int s, double *array, int nvar, int ncol = 0, bool on_halo_stream = false);
     // begin_ghost_exchange! in two halves, so that exchanges that begin at the same point of an
     // evaluation are packed one after the other and posted in ONE RCCL group
@@ -660,6 +670,7 @@ struct EngineT : EngineBase {
     }
     bool has_update_aux() const override { return P::HAS_UPDATE_AUX && P::update_aux_active(prm); }
     bool law_needs_gradflux() const override { return P::needs_gradflux(prm); }
+    bool gf_node_major() const override { return cmdg::gf_node_major<P>::value; }
     bool fused_update_aux() const override { return P::HAS_UPDATE_AUX && P::FUSE_UPDATE_AUX; }
     int law_nder() const override { return P::HAS_SOURCE ? P::NDER : 0; }
     int law_nupd() const override { return P::HAS_UPDATE_AUX ? P::NUPD : 0; }

@@ -218,6 +218,43 @@ struct has_flux_wavespeed<P, std::void_t<decltype(P::HAS_FLUX_WAVESPEED)>> : std
 // A law may also keep a few derived values per node (P::NCACHE doubles, P::node_cache) that its
 // first-order flux and wave speed are computed from: k_tendency then evaluates them once per
 // volume node and hands the staged copy to the minus side of the faces.
+// Laws whose state_gradient_flux the library keeps node-major, (NGF, Np, nelem), like
+// Qhypervisc_grad (cmdg_common.h): `static constexpr bool GF_NODE_MAJOR = true` in the functor.
+// The dry and the moist atmosphere take it (10-13 columns gathered on the plus side of every face
+// node); laws whose hooks or filters work on the array in the reference layout do not.
+#ifndef CMDG_GF_NODE_MAJOR
+#define CMDG_GF_NODE_MAJOR 1
+#endif
+template <class P, class = void>
+struct gf_node_major : std::false_type {
+};
+template <class P>
+struct gf_node_major<P, std::void_t<decltype(P::GF_NODE_MAJOR)>>
+    : std::integral_constant<bool, P::GF_NODE_MAJOR && CMDG_GF_NODE_MAJOR != 0 && (P::NGF > 0)> {
+};
+template <class P, int Np>
+__device__ __forceinline__ int64_t gf_at(int n, int s, int64_t e)
+{
+    return col_at<gf_node_major<P>::value, P::NGF, Np>(n, s, e);
+}
+template <class P, int Np>
+__device__ __forceinline__ void load_gf(Vec<P::NGF> &dst, const double *__restrict__ arr, int n, int64_t e)
+{
+#pragma unroll
+    for (int s = 0; s < P::NGF; ++s) dst[s] = arr[gf_at<P, Np>(n, s, e)];
+}
+template <class P, int Np>
+__device__ __forceinline__ void load_plus_gf(Vec<P::NGF> &dst, const double *__restrict__ arr,
+                                             const double *__restrict__ recv, int gslot, int vidP, int64_t eP)
+{
+    if (gslot >= 0) {
+#pragma unroll
+        for (int s = 0; s < P::NGF; ++s) dst[s] = recv[s + (int64_t)P::NGF * gslot];
+    } else {
+        load_gf<P, Np>(dst, arr, vidP, eP);
+    }
+}
+
 template <class P, class = void>
 struct node_cache_size : std::integral_constant<int, 0> {
 };
@@ -532,11 +569,11 @@ __device__ __forceinline__ void tendency_body(const PassArgs<P> &a)
                 if (use_gf) {
 #pragma unroll
                     for (int s = 0; s < NGF; ++s)
-                        sM[(NFA + s) * NSURF + sidx] = a.gf[tid + (int64_t)Np * (s + (int64_t)NGF * e)];
+                        sM[(NFA + s) * NSURF + sidx] = a.gf[gf_at<P, Np>(tid, s, e)];
                 }
 #pragma unroll
                 for (int s = 0; s < NHYP; ++s)
-                    sM[(NFA + NGFS + s) * NSURF + sidx] = a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)];
+                    sM[(NFA + NGFS + s) * NSURF + sidx] = a.hypgrad[hg_at<NHG, Np>(tid, s, e)];
             }
         }
     }
@@ -552,10 +589,10 @@ __device__ __forceinline__ void tendency_body(const PassArgs<P> &a)
         load_state<NAUX, Np>(laux, a.aux, tid, e);
 #pragma unroll
         for (int s = 0; s < NGF; ++s) lgf[s] = 0.0;
-        if (use_gf) load_state<NGF, Np>(lgf, a.gf, tid, e);
+        if (use_gf) load_gf<P, Np>(lgf, a.gf, tid, e);
 #pragma unroll
         for (int s = 0; s < NHYP; ++s)
-            lhyp[s] = a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)];
+            lhyp[s] = a.hypgrad[hg_at<NHG, Np>(tid, s, e)];
         const int sidx = surf_index<NQ, NQV>(tid);
         if constexpr (FACES) {
 #pragma unroll
@@ -727,13 +764,13 @@ __device__ __forceinline__ void tendency_body(const PassArgs<P> &a)
 #pragma unroll
                     for (int s = 0; s < NGF; ++s) gfM[s] = sM[(NFA + s) * NSURF + sidx];
                 } else {
-                    load_state<NGF, Np>(gfM, a.gf, fp.vidM, e);
+                    load_gf<P, Np>(gfM, a.gf, fp.vidM, e);
                 }
             }
 #pragma unroll
             for (int s = 0; s < NHYP; ++s)
                 hypM[s] = STAGE_M ? sM[(NFA + NGFS + s) * NSURF + sidx]
-                                  : a.hypgrad[fp.vidM + (int64_t)Np * (s + (int64_t)NHG * e)];
+                                  : a.hypgrad[hg_at<NHG, Np>(fp.vidM, s, e)];
 #pragma unroll
             for (int s = 0; s < NAUX; ++s) auxPn[s] = 0;
             if (shared_face) {  // plus side = the partner's staged minus side at the same face node
@@ -764,13 +801,13 @@ __device__ __forceinline__ void tendency_body(const PassArgs<P> &a)
                     for (int s = 0; s < NHYP; ++s) hypP[s] = sPp[(NFA + NGFS + s) * NPL];
                 }
             } else {
-                if (use_gf) load_plus<NGF, Np, NGF>(gfP, a.gf, a.h.recvGF, gslot, fp.vidP, fp.eP);
+                if (use_gf) load_plus_gf<P, Np>(gfP, a.gf, a.h.recvGF, gslot, fp.vidP, fp.eP);
                 load_plus<NS, Np, NS>(QPn, a.Q, a.h.recvQ, gslot, fp.vidP, fp.eP);
 #pragma unroll
                 for (int s = 0; s < NFA; ++s)
                     auxPn[P::face_aux(s)] =
                         a.aux[fp.vidP + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * fp.eP)];
-                load_plus<NHG, Np, NHYP>(hypP, a.hypgrad, a.h.recvHG, gslot, fp.vidP, fp.eP);
+                load_plus_hg<NHG, Np, NHYP>(hypP, a.hypgrad, a.h.recvHG, gslot, fp.vidP, fp.eP);
             }
 #pragma unroll
             for (int s = 0; s < NS; ++s) QPd[s] = QPn[s];
@@ -807,7 +844,7 @@ __device__ __forceinline__ void tendency_body(const PassArgs<P> &a)
                 if (f == 4) {  // bottom face: first interior node (:786-816)
                     load_state<NS, Np>(Q1, a.Q, n + NQ * NQ, e);
                     load_state<NAUX, Np>(aux1, a.aux, n + NQ * NQ, e);
-                    if (use_gf) load_state<NGF, Np>(gf1, a.gf, n + NQ * NQ, e);
+                    if (use_gf) load_gf<P, Np>(gf1, a.gf, n + NQ * NQ, e);
                 }
                 // numerical_boundary_flux_first_order!  NumericalFluxes.jl:163-205
                 P::boundary_state(a.prm, BS_FIRST, fp.bctag, QPn, auxPn, fp.n, QM, auxM, a_t, Q1,
@@ -940,9 +977,9 @@ __global__ void __launch_bounds__(256, 3) k_tendency_big(const PassArgs<P> a)
             load_state<NAUX, Np>(laux, a.aux, node, e);
 #pragma unroll
             for (int s = 0; s < NGF; ++s) lgf[s] = 0.0;
-            if (use_gf) load_state<NGF, Np>(lgf, a.gf, node, e);
+            if (use_gf) load_gf<P, Np>(lgf, a.gf, node, e);
 #pragma unroll
-            for (int s = 0; s < NHYP; ++s) lhyp[s] = a.hypgrad[node + (int64_t)Np * (s + (int64_t)NHG * e)];
+            for (int s = 0; s < NHYP; ++s) lhyp[s] = a.hypgrad[hg_at<NHG, Np>(node, s, e)];
             Vec<3 * NS> F, F2;
             F.negzero();
             P::flux_first_order(a.prm, F, lQ, laux, a_t, a.model_dir);
@@ -1053,12 +1090,12 @@ __global__ void __launch_bounds__(256, 3) k_tendency_big(const PassArgs<P> a)
                 for (int s = 0; s < NGF; ++s) gfM[s] = gfP[s] = 0.0;
                 const int gslot = RECV ? ghost_slot<Np>(a.h, fp.eP, fp.vidP) : -1;
                 if (use_gf) {
-                    load_state<NGF, Np>(gfM, a.gf, fp.vidM, e);
-                    load_plus<NGF, Np, NGF>(gfP, a.gf, a.h.recvGF, gslot, fp.vidP, fp.eP);
+                    load_gf<P, Np>(gfM, a.gf, fp.vidM, e);
+                    load_plus_gf<P, Np>(gfP, a.gf, a.h.recvGF, gslot, fp.vidP, fp.eP);
                 }
 #pragma unroll
                 for (int s = 0; s < NHYP; ++s)
-                    hypM[s] = a.hypgrad[fp.vidM + (int64_t)Np * (s + (int64_t)NHG * e)];
+                    hypM[s] = a.hypgrad[hg_at<NHG, Np>(fp.vidM, s, e)];
                 load_plus<NS, Np, NS>(QPn, a.Q, a.h.recvQ, gslot, fp.vidP, fp.eP);
 #pragma unroll
                 for (int s = 0; s < NAUX; ++s) auxPn[s] = 0;
@@ -1066,7 +1103,7 @@ __global__ void __launch_bounds__(256, 3) k_tendency_big(const PassArgs<P> a)
                 for (int s = 0; s < NFA; ++s)
                     auxPn[P::face_aux(s)] =
                         a.aux[fp.vidP + (int64_t)Np * (P::face_aux(s) + (int64_t)NAUX * fp.eP)];
-                load_plus<NHG, Np, NHYP>(hypP, a.hypgrad, a.h.recvHG, gslot, fp.vidP, fp.eP);
+                load_plus_hg<NHG, Np, NHYP>(hypP, a.hypgrad, a.h.recvHG, gslot, fp.vidP, fp.eP);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) QPd[s] = QPn[s];
 #pragma unroll
@@ -1097,7 +1134,7 @@ __global__ void __launch_bounds__(256, 3) k_tendency_big(const PassArgs<P> a)
                     if (f == 4) {
                         load_state<NS, Np>(Q1, a.Q, n + NQ * NQ, e);
                         load_state<NAUX, Np>(aux1, a.aux, n + NQ * NQ, e);
-                        if (use_gf) load_state<NGF, Np>(gf1, a.gf, n + NQ * NQ, e);
+                        if (use_gf) load_gf<P, Np>(gf1, a.gf, n + NQ * NQ, e);
                     }
                     P::boundary_state(a.prm, BS_FIRST, fp.bctag, QPn, auxPn, fp.n, QM, auxM, a_t, Q1, aux1);
                     nf_first_order<P>(a.prm, a.nf_first, flux, fp.n, QM, auxM, QPn, auxPn, a_t, facedir, nullptr);
@@ -1444,13 +1481,21 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::Np > 125 ? CMDG_GRAD_BOUND_LA
         __syncthreads();
     }
     if (tid < Np) {
+        if constexpr (!gf_node_major<P>::value) {
 #pragma unroll
-        for (int s = 0; s < NGF; ++s)
-            a.gf[tid + (int64_t)Np * (s + (int64_t)P::NGF * e)] = sA[s * Np + tid];
+            for (int s = 0; s < NGF; ++s)
+                a.gf[tid + (int64_t)Np * (s + (int64_t)P::NGF * e)] = sA[s * Np + tid];
+        }
+        if constexpr (!CMDG_HG_NODE_MAJOR) {
 #pragma unroll
-        for (int s = 0; s < NHG; ++s)
-            a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)] = sA[(NGF + s) * Np + tid];
+            for (int s = 0; s < NHG; ++s)
+                a.hypgrad[hg_at<NHG, Np>(tid, s, e)] = sA[(NGF + s) * Np + tid];
+        }
     }
+    if constexpr (gf_node_major<P>::value && NGF > 0)
+        store_node_major<P::NGF, Np, NGF>(a.gf, e, tid, (int)blockDim.x, sA);
+    if constexpr (CMDG_HG_NODE_MAJOR && NHG > 0)
+        store_node_major<NHG, Np, NHG>(a.hypgrad, e, tid, (int)blockDim.x, sA + NGF * Np);
     if constexpr (NGF > 0)
         send_nodes<P::NGF, NGF>(a.h, 0, e, tid, (int)blockDim.x, [&](int s, int n) { return sA[s * Np + n]; });
     if constexpr (NHG > 0)
@@ -1494,11 +1539,12 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT)) k_divgrad(const PassArgs
             x21 = vg[XI2X1 * Np], x22 = vg[XI2X2 * Np], x23 = vg[XI2X3 * Np];
         }
         if (vt) x31 = vg[XI3X1 * Np], x32 = vg[XI3X2 * Np], x33 = vg[XI3X3 * Np];
+        Vec<NHG> G;  // (all of them in flight before the first LDS store: -17 % on this pass)
+#pragma unroll
+        for (int q = 0; q < NHG; ++q) G[q] = a.hypgrad[hg_at<NHG, Np>(tid, q, e)];
 #pragma unroll
         for (int s = 0; s < NGL; ++s) {
-            const double G1 = a.hypgrad[tid + (int64_t)Np * (3 * s + 0 + (int64_t)NHG * e)];
-            const double G2 = a.hypgrad[tid + (int64_t)Np * (3 * s + 1 + (int64_t)NHG * e)];
-            const double G3 = a.hypgrad[tid + (int64_t)Np * (3 * s + 2 + (int64_t)NHG * e)];
+            const double G1 = G[3 * s + 0], G2 = G[3 * s + 1], G3 = G[3 * s + 2];
             if (hz) {
                 sC[(0 * NG + s) * Np + tid] = M * (x11 * G1 + x12 * G2 + x13 * G3);
                 sC[(1 * NG + s) * Np + tid] = M * (x21 * G1 + x22 * G2 + x23 * G3);
@@ -1547,7 +1593,7 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT)) k_divgrad(const PassArgs
             const int sidx = surf_index<NQ, NQV>(fp.vidM);
 #pragma unroll
             for (int q = 0; q < NHG; ++q) gM[q] = sM[q * NSURF + sidx];
-            load_plus<NHG, Np, NHG>(gP, a.hypgrad, a.h.recvHG, ghost_slot<Np>(a.h, fp.eP, fp.vidP),
+            load_plus_hg<NHG, Np, NHG>(gP, a.hypgrad, a.h.recvHG, ghost_slot<Np>(a.h, fp.eP, fp.vidP),
                                     fp.vidP, fp.eP);
             if (fp.bctag != 0) {  // numerical_boundary_flux_divergence!  :732-763
                 Vec<NAUX> auxM, auxP;
@@ -1609,9 +1655,11 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_LAP_MINW) k_gradlap
     }
     const bool hz = a.direction != DIR_VERTICAL, vt = a.direction != DIR_HORIZONTAL;
     if (tid < Np) {
+        Vec<NGL> l;  // (all loads in flight before the first LDS store, as in k_divgrad)
 #pragma unroll
-        for (int s = 0; s < NGL; ++s)
-            sL[s * Np + tid] = a.hypdiv[tid + (int64_t)Np * (s + (int64_t)NHYP * e)];
+        for (int s = 0; s < NGL; ++s) l[s] = a.hypdiv[tid + (int64_t)Np * (s + (int64_t)NHYP * e)];
+#pragma unroll
+        for (int s = 0; s < NGL; ++s) sL[s * Np + tid] = l[s];
     }
     __syncthreads();
     if (tid < Np) {
@@ -1711,10 +1759,12 @@ __global__ void __launch_bounds__((KDims<NQ, NQV>::NT), CMDG_LAP_MINW) k_gradlap
         }
         __syncthreads();
     }
-    if (tid < Np) {
+    if constexpr (CMDG_HG_NODE_MAJOR) {
+        if constexpr (NHYP > 0) store_node_major<NHG, Np, NHYP>(a.hypgrad, e, tid, (int)blockDim.x, sA);
+    } else if (tid < Np) {
 #pragma unroll
         for (int s = 0; s < NHYP; ++s)
-            a.hypgrad[tid + (int64_t)Np * (s + (int64_t)NHG * e)] = sA[s * Np + tid];
+            a.hypgrad[hg_at<NHG, Np>(tid, s, e)] = sA[s * Np + tid];
     }
     if constexpr (NHYP > 0)
         send_nodes<NHG, NHYP>(a.h, 0, e, tid, (int)blockDim.x, [&](int s, int n) { return sA[s * Np + n]; });
@@ -1771,7 +1821,7 @@ __global__ void k_init_derived(typename P::Params prm, const double *aux, double
 // the reference packs whole arrays, nvar == ncol)
 static __global__ void k_fillsendbuf(double *__restrict__ sendbuf, const double *__restrict__ buf,
                               const int64_t *__restrict__ vmapsend, int64_t nvmap, int Np,
-                              int nvar, int ncol)
+                              int nvar, int ncol, int node_major = 0)
 {
     const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= nvmap * nvar) return;
@@ -1779,11 +1829,12 @@ static __global__ void k_fillsendbuf(double *__restrict__ sendbuf, const double 
     const int s = (int)(I % nvar);
     const int64_t id = vmapsend[i] - 1;
     const int64_t e = id / Np, n = id % Np;
-    sendbuf[s + (int64_t)nvar * i] = buf[n + (int64_t)Np * (s + (int64_t)ncol * e)];
+    sendbuf[s + (int64_t)nvar * i] = node_major ? buf[s + (int64_t)ncol * (n + (int64_t)Np * e)]
+                                                : buf[n + (int64_t)Np * (s + (int64_t)ncol * e)];
 }
 static __global__ void k_transferrecvbuf(double *__restrict__ buf, const double *__restrict__ recvbuf,
                                   const int64_t *__restrict__ vmaprecv, int64_t nvmap, int Np,
-                                  int nvar, int ncol)
+                                  int nvar, int ncol, int node_major = 0)
 {
     const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= nvmap * nvar) return;
@@ -1791,7 +1842,30 @@ static __global__ void k_transferrecvbuf(double *__restrict__ buf, const double 
     const int s = (int)(I % nvar);
     const int64_t id = vmaprecv[i] - 1;
     const int64_t e = id / Np, n = id % Np;
-    buf[n + (int64_t)Np * (s + (int64_t)ncol * e)] = recvbuf[s + (int64_t)nvar * i];
+    buf[node_major ? s + (int64_t)ncol * (n + (int64_t)Np * e) : n + (int64_t)Np * (s + (int64_t)ncol * e)] =
+        recvbuf[s + (int64_t)nvar * i];
+}
+
+// ---------------------------------------------------------------------------------
+// A node-major array of the library (ncol, Np, nelem) into the reference layout (Np, ncol, nelem) of
+// a caller that asked for it (create_states.jl:17-26), and back.
+static __global__ void k_export_node_major(double *__restrict__ dst, const double *__restrict__ src, int Np,
+                                           int ncol, int64_t nelem)
+{
+    const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= (int64_t)Np * ncol * nelem) return;
+    const int64_t e = I / ((int64_t)Np * ncol);
+    const int r = (int)(I - e * Np * ncol), s = r / Np, n = r - s * Np;
+    dst[I] = src[s + (int64_t)ncol * (n + (int64_t)Np * e)];
+}
+static __global__ void k_import_node_major(double *__restrict__ dst, const double *__restrict__ src, int Np,
+                                           int ncol, int64_t nelem)
+{
+    const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= (int64_t)Np * ncol * nelem) return;
+    const int64_t e = I / ((int64_t)Np * ncol);
+    const int r = (int)(I - e * Np * ncol), n = r / ncol, s = r - n * ncol;
+    dst[I] = src[n + (int64_t)Np * (s + (int64_t)ncol * e)];
 }
 
 // ---------------------------------------------------------------------------------
@@ -1868,7 +1942,7 @@ __global__ __launch_bounds__((KDims<NQ, NQV>::Np <= 128 ? 128 : 256)) void k_cou
             Vec<P::NGF> lG;
             load_state<P::NS, Np>(lQ, Q, n, e);
             load_state<P::NAUX, Np>(lA, aux, n, e);
-            if constexpr (P::NGF > 0) load_state<P::NGF, Np>(lG, gf, n, e);
+            if constexpr (P::NGF > 0) load_gf<P, Np>(lG, gf, n, e);
             val = fmax(val, P::courant(prm, kind, lQ, lA, lG, md, dt, t, direction));
         }
     }

@@ -50,6 +50,7 @@ struct DryAtmos {
     static constexpr int NGRAD = 4 + (SMAG ? 1 : 0) + (HYPER ? 4 : 0);
     // GradientFlux: grad h_tot, S, [N^2]
     static constexpr int NGF = 9 + (SMAG ? 1 : 0);
+    static constexpr bool GF_NODE_MAJOR = true;  // kernels.h gf_node_major
     static constexpr int NGL = HYPER ? 4 : 0;
     static constexpr int NHYP = HYPER ? 12 : 0;
     static constexpr bool HAS_UPDATE_AUX = true;

@@ -42,6 +42,8 @@ struct MoistAtmos {
     static constexpr int OPHI = 3, OREF = 7, OTURB = 14, OMOIST = 15;
     static constexpr int NGT = CLOSURE == 2 ? 10 : 7;  // turbulence block of the gradient flux
     static constexpr int NS = 6, NAUX = 19, NGRAD = 6, NGF = 3 + NGT + 3, NGL = 0, NHYP = 0;
+    // (state_gradient_flux stays in the reference layout: node-major, as the dry law keeps it, takes 88 B/node
+    // off the N = 6 tendency pass and not one microsecond -- profiles/r04_ab_node_major.txt)
     // the nodal refresh (one saturation adjustment per node) runs as its own pass before the
     // gradient kernel, as in the reference; the kernels then read temperature, theta_v and the
     // condensate from the auxiliary state instead of repeating the adjustment where the

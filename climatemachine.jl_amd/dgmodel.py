@@ -82,8 +82,8 @@ class DGModel:
             law.rebalance_reference_state(g, aux, gradp)
         self.state_auxiliary = _dev(aux, dev) if isinstance(aux, np.ndarray) else aux
         ne, Np = g.nelem, g.Np
-        self.state_gradient_flux = torch.zeros((ne, max(law.ngradflux, 1), Np), dtype=torch.float64, device=dev)
-        self.Qhypervisc_grad = torch.zeros((ne, max(3 * law.ngradlap, 1), Np), dtype=torch.float64, device=dev)
+        self._gradient_flux = torch.zeros((ne, max(law.ngradflux, 1), Np), dtype=torch.float64, device=dev)
+        self._hypervisc_grad = None         # reference layout, on demand (Qhypervisc_grad)
         self.Qhypervisc_div = torch.zeros((ne, max(law.nhyper, 1), Np), dtype=torch.float64, device=dev)
         d = _lib.CmdgDesc()
         d.dim = 3
@@ -111,8 +111,8 @@ class DGModel:
         d.nabrtovmapsend = self._nsend.ctypes.data
         d.nabrtovmaprecv = self._nrecv.ctypes.data
         d.state_auxiliary = self.state_auxiliary.data_ptr()
-        d.state_gradient_flux = self.state_gradient_flux.data_ptr()
-        d.Qhypervisc_grad = self.Qhypervisc_grad.data_ptr()
+        d.state_gradient_flux = self._gradient_flux.data_ptr()
+        d.Qhypervisc_grad = 0               # the library's working copy is node-major (cmdg.h)
         d.Qhypervisc_div = self.Qhypervisc_div.data_ptr()
         torch.cuda.synchronize(dev)          # tables uploaded on torch's stream
         h = C.c_void_p()
@@ -133,6 +133,28 @@ class DGModel:
         elements refreshed, as the reference does (default: exterior launches write the send
         buffers, face kernels read the receive buffers)."""
         _lib.check(self.L.cmdg_set_option(self.handle, int(option), int(value)), self.handle)
+
+    @property
+    def state_gradient_flux(self):
+        """``dg.state_gradient_flux`` as the reference holds it, ``(nelem, ngradflux, Np)``
+        (``cmdg_export_gradient_flux``: a copy out of the node-major working array for the
+        atmosphere laws, the working array itself otherwise)."""
+        if self.balance_law.ngradflux > 0:
+            _lib.check(self.L.cmdg_export_gradient_flux(self.handle, self._gradient_flux.data_ptr()), self.handle)
+        return self._gradient_flux
+
+    @property
+    def Qhypervisc_grad(self):
+        """``dg.states_higher_order[1]`` as the reference holds it, ``(nelem, 3 ngradlap, Np)``:
+        ``cmdg_export_hypervisc_grad`` (the library's working copy is node-major; this is a
+        copy made at the time of the call)."""
+        g, law = self.grid, self.balance_law
+        if self._hypervisc_grad is None:
+            self._hypervisc_grad = torch.zeros((g.nelem, max(3 * law.ngradlap, 1), g.Np), dtype=torch.float64,
+                                               device=self.device)
+        if law.ngradlap > 0:
+            _lib.check(self.L.cmdg_export_hypervisc_grad(self.handle, self._hypervisc_grad.data_ptr()), self.handle)
+        return self._hypervisc_grad
 
     def query(self, item):
         """``cmdg_query``: what the handle's kernels do (``_lib.CMDG_Q`` names, e.g.

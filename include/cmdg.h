@@ -113,8 +113,10 @@ typedef struct cmdg_desc {
     /* arrays owned by the `dg` in the reference; device pointers, caller-owned.
      * state_auxiliary is required; the other three may be NULL (library allocates). */
     double *state_auxiliary;       /* (Np, naux, nelem) */
-    double *state_gradient_flux;   /* (Np, ngradflux, nelem) */
-    double *Qhypervisc_grad;       /* (Np, 3*ngradlap, nelem)  create_states.jl:22-26 */
+    double *state_gradient_flux;   /* (Np, ngradflux, nelem); physics_id 2: filled by
+                                      cmdg_export_gradient_flux only (see there) */
+    double *Qhypervisc_grad;       /* (Np, 3*ngradlap, nelem)  create_states.jl:22-26; filled by
+                                      cmdg_export_hypervisc_grad only (see there) */
     double *Qhypervisc_div;        /* (Np, nhyper, nelem) */
     const double *Dv;              /* HOST pointer, (Nqv, Nqv) column-major, grid.D[end]; may be
                                       NULL when N[2] == N[0] */
@@ -281,6 +283,21 @@ enum {
     CMDG_Q_STATE_READ = 16, CMDG_Q_AUX_READ = 20
 };
 int cmdg_query(cmdg_handle h, int32_t what, int64_t *out);
+
+/* dg.states_higher_order[1] (Qhypervisc_grad, create_states.jl:22-26) in the reference layout
+ * (Np, 3*ngradlap, nelem).  The library keeps its working copy node-major -- (3*ngradlap, Np,
+ * nelem): the 3*ngradlap values of a node are contiguous, which is what a plus-side face gather of
+ * the Laplacian and tendency passes reads -- so cmdg_desc.Qhypervisc_grad is
+ * NOT written by an evaluation; this call writes the array as the reference would hold it after
+ * the last evaluation (`dst`, or cmdg_desc.Qhypervisc_grad if dst is NULL) and returns when the
+ * copy is complete.  Ghost elements as described for CMDG_OPT_REFERENCE_HALO.  For diagnostics
+ * and tests: nothing on the hot path reads the reference layout. */
+int cmdg_export_hypervisc_grad(cmdg_handle h, double *dst);
+/* The same for dg.state_gradient_flux, (Np, ngradflux, nelem).  For the dry atmosphere (physics_id 2)
+ * the library's working copy is node-major as well and cmdg_desc.state_gradient_flux is
+ * written by this call only; for every other law the array of cmdg_desc IS the working copy (hooks
+ * and filters address it) and the call is a no-op (dst NULL or that array) or a copy. */
+int cmdg_export_gradient_flux(cmdg_handle h, double *dst);
 
 /* ---- halo (MPIStateArrays.jl:411-514, 837-871) -------------------------------- */
 /* begin_ghost_exchange!: pack face nodes of `array` (Np, nstate, nelem) and post the

@@ -68,3 +68,15 @@ def test_nested_handle_may_be_destroyed_first(cm, torch):
     for f in (odg.fu, odg.ft):
         f.close()
     odg.dg.close()
+
+
+def test_gradient_flux_copies_are_refused_on_a_node_major_law(cm, torch):
+    """``cmdg_set_rhs_hooks`` with gradient-flux -> auxiliary copies addresses ``state_gradient_flux``
+    in the reference layout; the dry atmosphere keeps it node-major (cmdg.h,
+    ``cmdg_export_gradient_flux``) and says so instead of copying the wrong numbers."""
+    from helpers import rising_bubble_setup
+    law, grid = rising_bubble_setup(nx=2, ny=2, nz=2)
+    dg = cm.dgmodel.DGModel(law, grid)
+    with pytest.raises(RuntimeError, match="node-major"):
+        dg.set_rhs_hooks(gradflux_to_aux=[(0, law.naux - 1, 1.0)])
+    dg.close()

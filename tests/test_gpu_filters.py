@@ -200,6 +200,42 @@ def test_gradient_and_tendency_filters_in_the_operator(cm, oracle, torch):
     dg.close()
 
 
+def test_gradient_filter_on_a_node_major_gradient_flux(cm, oracle, torch):
+    """The dry atmosphere's ``state_gradient_flux`` is node-major inside the library (cmdg.h,
+    ``cmdg_export_gradient_flux``); a ``gradient_filter`` then runs on a reference-layout copy that
+    is folded back.  Operator and exported array against the oracle, then the filter removed."""
+    from helpers import rising_bubble_setup
+    F = cm.mesh.filters
+    law, grid = rising_bubble_setup(nx=3, ny=2, nz=3)
+    dg = cm.dgmodel.DGModel(law, grid)
+    odg = oracle.OracleDGModel(law, grid)
+    gfilt = F.ExponentialFilter(grid, 1, 8)
+    gt = F.FilterIndices(range(1, law.ngradflux + 1))
+    odg.gradient_filter = (gfilt, gt)
+    gdev = F.make_device_filter(dg, gfilt, gt, nstate=law.ngradflux)
+    dg.set_filters(gradient_filter=gdev)
+    Q0 = law.init_state_prognostic(grid, odg.state_auxiliary, 0.0)
+    rng = np.random.default_rng(5)
+    Q0[:, 1:4] += Q0[:, 0:1] * 2.0 * rng.standard_normal(Q0[:, 1:4].shape)
+    To, T1 = np.zeros_like(Q0), np.zeros_like(Q0)
+    odg(To, Q0.copy(), 0.2, 1.0, 0.0)
+    Tg = _gpu(torch, np.zeros_like(Q0))
+    dg(Tg, _gpu(torch, Q0), 0.2, 1.0, 0.0)
+    assert rel_linf(Tg.cpu().numpy(), To) < TOL
+    gfg = dg.state_gradient_flux.cpu().numpy()
+    for s in range(law.ngradflux):
+        sc = max(np.abs(odg.state_gradient_flux[:, s]).max(), 1e-300)
+        assert np.abs(gfg[:, s] - odg.state_gradient_flux[:, s]).max() / sc < TOL, s
+    dg.set_filters()
+    odg.gradient_filter = None
+    odg(T1, Q0.copy(), 0.2, 1.0, 0.0)
+    dg(Tg, _gpu(torch, Q0), 0.2, 1.0, 0.0)
+    assert rel_linf(Tg.cpu().numpy(), T1) < TOL
+    assert rel_linf(T1, To) > 1e-8          # the filter was not a no-op
+    gdev.close()
+    dg.close()
+
+
 def test_step_filter_in_lsrk_run(cm, oracle, torch):
     """Held-Suarez time loop with the exponential filter after every step
     (heldsuarez.jl:261-272), three steps, against the oracle."""
