@@ -19,6 +19,15 @@
 #include "cmdg_common.h"
 
 // minimum waves per SIMD requested from the register allocator (tuning knobs)
+// Memory round trips of the tendency pass issued as early as they can be (bits: 1 = the old tendency
+// of all states in one batch instead of one dependent load per state inside the contraction; 2 =
+// the metric rows with the state, before the flux arithmetic, where that does not cost residency).
+// The pass is bound by its chain of dependent loads, not by bytes (profiles/r04_ab_tendency_hoist.txt;
+// pinning every plus-side gather of a face node before the first-order flux was the third candidate
+// and lost).
+#ifndef CMDG_TEND_HOIST
+#define CMDG_TEND_HOIST 3
+#endif
 #ifndef CMDG_TEND_MINW
 #define CMDG_TEND_MINW 1
 #endif
@@ -585,6 +594,19 @@ __device__ __forceinline__ void tendency_body(const PassArgs<P> &a)
         Vec<NAUX> laux;
         Vec<NGF> lgf;
         Vec<NHYP> lhyp;
+        double x11 = 0, x12 = 0, x13 = 0, x21 = 0, x22 = 0, x23 = 0, x31 = 0, x32 = 0, x33 = 0;
+        // the metric rows with the first batch of loads -- unless that costs a work-group of
+        // residency: the hyperdiffusive inviscid instantiation at N <= 4 (Held-Suarez) sits at 126
+        // VGPRs, five work-groups per CU; with nine more doubles live across the flux arithmetic it
+        // takes 148 and runs on four (661 us against 636; rising bubble 132 -> 124 us, BOMEX 589 -> 578)
+        constexpr bool METRICS_FIRST = (CMDG_TEND_HOIST & 2) != 0 && !(NHYP > 0 && !use_gf && Np <= 125 && NS >= 5);
+        if constexpr (METRICS_FIRST) {
+            if (hz) {
+                x11 = vg[XI1X1 * Np], x12 = vg[XI1X2 * Np], x13 = vg[XI1X3 * Np];
+                x21 = vg[XI2X1 * Np], x22 = vg[XI2X2 * Np], x23 = vg[XI2X3 * Np];
+            }
+            if (vt) x31 = vg[XI3X1 * Np], x32 = vg[XI3X2 * Np], x33 = vg[XI3X3 * Np];
+        }
         load_state<NS, Np>(lQ, a.Q, tid, e);
         load_state<NAUX, Np>(laux, a.aux, tid, e);
 #pragma unroll
@@ -593,6 +615,7 @@ __device__ __forceinline__ void tendency_body(const PassArgs<P> &a)
 #pragma unroll
         for (int s = 0; s < NHYP; ++s)
             lhyp[s] = a.hypgrad[hg_at<NHG, Np>(tid, s, e)];
+        if constexpr (METRICS_FIRST) __builtin_amdgcn_sched_barrier(0);  // (all of them in flight here)
         const int sidx = surf_index<NQ, NQV>(tid);
         if constexpr (FACES) {
 #pragma unroll
@@ -640,8 +663,10 @@ __device__ __forceinline__ void tendency_body(const PassArgs<P> &a)
 #pragma unroll
         for (int q = 0; q < 3 * NS; ++q) F[q] += F2[q];
         if (hz) {
-            const double x11 = vg[XI1X1 * Np], x12 = vg[XI1X2 * Np], x13 = vg[XI1X3 * Np];
-            const double x21 = vg[XI2X1 * Np], x22 = vg[XI2X2 * Np], x23 = vg[XI2X3 * Np];
+            if constexpr (!METRICS_FIRST) {
+                x11 = vg[XI1X1 * Np], x12 = vg[XI1X2 * Np], x13 = vg[XI1X3 * Np];
+                x21 = vg[XI2X1 * Np], x22 = vg[XI2X2 * Np], x23 = vg[XI2X3 * Np];
+            }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const double F1 = F[3 * s], F2_ = F[3 * s + 1], F3 = F[3 * s + 2];
@@ -650,7 +675,9 @@ __device__ __forceinline__ void tendency_body(const PassArgs<P> &a)
             }
         }
         if (vt) {
-            const double x31 = vg[XI3X1 * Np], x32 = vg[XI3X2 * Np], x33 = vg[XI3X3 * Np];
+            // (both directions' rows in ONE late batch were tried too: nine doubles live across the two
+            // blocks cost the same 24 VGPRs as the early batch)
+            if constexpr (!METRICS_FIRST) x31 = vg[XI3X1 * Np], x32 = vg[XI3X2 * Np], x33 = vg[XI3X3 * Np];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const double F1 = F[3 * s], F2_ = F[3 * s + 1], F3 = F[3 * s + 2];
@@ -670,11 +697,21 @@ __device__ __forceinline__ void tendency_body(const PassArgs<P> &a)
     Vec<NS> Tv;
     if (VOL && live && tid < Np) {
         const int i = tid % NQ, j = (tid / NQ) % NQ, k = tid / (NQ * NQ);
+        Vec<NS> Tprev;
+        if constexpr ((CMDG_TEND_HOIST & 1) != 0) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) Tprev[s] = 0.0;
+            if (a.beta != 0) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) Tprev[s] = a.tendency[tid + (int64_t)Np * (s + (int64_t)NS * e)];
+            }
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             double T = 0.0;
-            const double Told =
-                a.beta != 0 ? a.tendency[tid + (int64_t)Np * (s + (int64_t)NS * e)] : 0.0;
+            const double Told = (CMDG_TEND_HOIST & 1) != 0
+                                    ? Tprev[s]
+                                    : (a.beta != 0 ? a.tendency[tid + (int64_t)Np * (s + (int64_t)NS * e)] : 0.0);
             if (hz) {  // generic kernel called with HorizontalDirection() (:64-309)
                 double lt = 0.0;
                 if (a.direction == DIR_HORIZONTAL && P::HAS_SOURCE) lt += S[s];
