@@ -224,13 +224,11 @@ template <class P>
 struct has_flux_wavespeed<P, std::void_t<decltype(P::HAS_FLUX_WAVESPEED)>> : std::true_type {
 };
 
-// A law may also keep a few derived values per node (P::NCACHE doubles, P::node_cache) that its
-// first-order flux and wave speed are computed from: k_tendency then evaluates them once per
-// volume node and hands the staged copy to the minus side of the faces.
 // Laws whose state_gradient_flux the library keeps node-major, (NGF, Np, nelem), like
 // Qhypervisc_grad (cmdg_common.h): `static constexpr bool GF_NODE_MAJOR = true` in the functor.
-// The dry and the moist atmosphere take it (10-13 columns gathered on the plus side of every face
-// node); laws whose hooks or filters work on the array in the reference layout do not.
+// The dry atmosphere takes it (10 columns gathered on the plus side of every face node; the moist
+// law was measured and keeps the reference layout, physics_moist.h); laws whose hooks work on the
+// array in the reference layout do not.
 #ifndef CMDG_GF_NODE_MAJOR
 #define CMDG_GF_NODE_MAJOR 1
 #endif
@@ -264,6 +262,9 @@ __device__ __forceinline__ void load_plus_gf(Vec<P::NGF> &dst, const double *__r
     }
 }
 
+// A law may also keep a few derived values per node (P::NCACHE doubles, P::node_cache) that its
+// first-order flux and wave speed are computed from: k_tendency then evaluates them once per
+// volume node and hands the staged copy to the minus side of the faces.
 template <class P, class = void>
 struct node_cache_size : std::integral_constant<int, 0> {
 };
