@@ -1477,9 +1477,9 @@ bool EngineBase::filter_pair(double *Q)
     prof_begin(CMDG_K_FILTER, s_comp);
 #define CMDG_FP_CASE(N)                                                                                    \
     case N:                                                                                                \
-        hipLaunchKernelGGL((k_apply_vfilter_pair<N>), dim3((unsigned)nreal), dim3(FDims<N>::NT),           \
-                           sizeof(double) * 2 * a.nfs * FDims<N>::Np, s_comp, a, (const double *)f2->d_Fv, \
-                           f1->nindices);                                                                  \
+        hipLaunchKernelGGL((k_apply_vfilter_pair<N>),                                                      \
+                           dim3((unsigned)(((int64_t)N * N * a.nfs * nreal + 255) / 256)), dim3(256), 0,   \
+                           s_comp, a, (const double *)f2->d_Fv, f1->nindices);                             \
         break;
     switch (NQ) {
         CMDG_FP_CASE(2) CMDG_FP_CASE(3) CMDG_FP_CASE(4) CMDG_FP_CASE(5) CMDG_FP_CASE(6) CMDG_FP_CASE(7)

@@ -191,41 +191,40 @@ __global__ __launch_bounds__(FDims<NQ>::NT) void k_apply_filter(FilterArgs a)
 // hydrostatic_boussinesq_model.jl:654-680): a state's result depends on its own column and its own
 // filter matrix only, so the values are those of the two launches.  The first nfa filtered states
 // of a.idx take Fv, the rest Fv2.
+// One thread = one vertical line of one filtered state: its NQ values into registers, the NQ x NQ
+// product in the reference's summation order, NQ stores -- no staging of the element, no barrier
+// but the one behind the two matrices.  (The one-element-per-work-group form before it moved 6 KB per
+// work-group behind two barriers: 85 us per launch on the 48 x 48 x 16 box where the bytes take 40.)
 template <int NQ>
-__global__ __launch_bounds__(FDims<NQ>::NT) void k_apply_vfilter_pair(FilterArgs a, const double *__restrict__ Fv2,
-                                                                     int nfa)
+__global__ __launch_bounds__(256) void k_apply_vfilter_pair(FilterArgs a, const double *__restrict__ Fv2, int nfa)
 {
-    constexpr int Np = FDims<NQ>::Np, NT = FDims<NQ>::NT;
-    extern __shared__ double lds[];
+    constexpr int Nij = NQ * NQ, Np = FDims<NQ>::Np;
     __shared__ double sFa[NQ * NQ], sFb[NQ * NQ];
     const int tid = threadIdx.x;
-    const int64_t e = xcd_remap(blockIdx.x, gridDim.x);
-    const int nfs = a.nfs;
-    double *cur = lds, *nxt = lds + nfs * Np;
     if (tid < NQ * NQ) {
         sFa[tid] = a.Fv[tid];
         sFb[tid] = Fv2[tid];
     }
-    double *Qe = a.Q + (int64_t)Np * a.nstate * e;
-    for (int w = tid; w < nfs * Np; w += NT) {
-        const int fs = w / Np, ijk = w - fs * Np;
-        cur[w] = Qe[ijk + Np * (a.idx[fs] - 1)];
-    }
     __syncthreads();
-    for (int w = tid; w < nfs * Np; w += NT) {  // filter_pass<NQ, 2> with the state's own matrix
-        const int ijk = w % Np, kq = ijk / (NQ * NQ);
-        const double *sF = w / Np < nfa ? sFa : sFb;
-        const double *col = cur + (w - kq * NQ * NQ);
+    const int nfs = a.nfs;
+    const int64_t line = (int64_t)blockIdx.x * blockDim.x + tid;  // (ij, filtered state, element)
+    if (line >= (int64_t)Nij * nfs * a.nreal) return;
+    const int64_t e = line / (Nij * nfs);
+    const int r = (int)(line - e * (Nij * nfs)), fs = r / Nij, ij = r - fs * Nij;
+    double *col = a.Q + ij + (int64_t)Np * ((a.idx[fs] - 1) + (int64_t)a.nstate * e);
+    const double *sF = fs < nfa ? sFa : sFb;
+    double v[NQ], o[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) v[n] = col[n * Nij];
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq) {  // filter_pass<NQ, 2> with the state's own matrix
         double acc = 0.0;
 #pragma unroll
-        for (int n = 0; n < NQ; ++n) acc += sF[kq + NQ * n] * col[n * NQ * NQ];
-        nxt[w] = acc;
+        for (int n = 0; n < NQ; ++n) acc += sF[kq + NQ * n] * v[n];
+        o[kq] = acc;
     }
-    __syncthreads();
-    for (int w = tid; w < nfs * Np; w += NT) {
-        const int fs = w / Np, ijk = w - fs * Np;
-        Qe[ijk + Np * (a.idx[fs] - 1)] = nxt[w];
-    }
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq) col[kq * Nij] = o[kq];
 }
 
 // the reference's shared-memory tree (Filters.jl:848-861, 1047-1060): for n = 11..1, if
