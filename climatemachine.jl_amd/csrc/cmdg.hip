@@ -1895,6 +1895,16 @@ int load_plugin(const char *path, std::string &err)
         dlclose(lib);
         return CMDG_ERR_INVALID;
     }
+    // a plug-in shares the C++ layout of EngineBase with the library: one built against other
+    // headers is refused here instead of corrupting a handle later
+    typedef unsigned long (*plugin_abi_t)();
+    plugin_abi_t abi = (plugin_abi_t)dlsym(lib, "cmdg_plugin_abi");
+    if (!abi || abi() != engine_abi_stamp()) {
+        err = std::string(path) + (abi ? " was built against another libcmdg (engine layout differs): rebuild it"
+                                       : " does not export cmdg_plugin_abi");
+        dlclose(lib);
+        return CMDG_ERR_INVALID;
+    }
     g_plugin_make.push_back(f);
     g_plugin_path.push_back(path);
     return CMDG_OK;

@@ -693,6 +693,14 @@ struct EngineT : EngineBase {
     }
 };
 
+// what a plug-in and the library must agree on (cmdg_load_plugin): the layout of the engine base
+// class and of the descriptor, folded into one number
+inline unsigned long engine_abi_stamp()
+{
+    return (unsigned long)sizeof(EngineBase) * 1000003ul + (unsigned long)sizeof(cmdg_desc) * 10007ul +
+           (unsigned long)sizeof(RhsCtx) * 101ul + (unsigned long)sizeof(cmdg_rhs_hooks);
+}
+
 template <class P, int NQ_, int NQV_ = NQ_>
 EngineBase *make_engine(const cmdg_desc *d)
 {

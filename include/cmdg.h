@@ -150,7 +150,9 @@ int cmdg_destroy(cmdg_handle h);
  * plug-in: a shared object built from this library's own kernel headers (csrc/engine.h + a
  * physics_*.h device functor, one translation unit instantiating make_engine<Law, Nq>) that exports
  *   cmdg::EngineBase *cmdg_plugin_make_engine(const cmdg_desc *, char *err, int errlen)
- * and returns NULL for descriptors it does not serve.  cmdg_create asks the loaded plug-ins when no
+ * and returns NULL for descriptors it does not serve, and
+ *   unsigned long cmdg_plugin_abi(void)        -- engine_abi_stamp() of the headers it was built with;
+ * a plug-in built against other headers than this library is refused at load.  cmdg_create asks the loaded plug-ins when no
  * compiled-in engine takes a descriptor (a law the library knows in a combination or at an order
  * it was not built for, or a physics_id of the plug-in's own).  cmdg_load_plugin loads one
  * (idempotent; CMDG_ERR_INVALID with the reason in cmdg_last_error(NULL)); the environment variable

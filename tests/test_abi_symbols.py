@@ -101,3 +101,22 @@ def test_engine_plugin_builds_and_loads():
     L.cmdg_last_error.restype = C.c_char_p
     assert L.cmdg_load_plugin(b"/nonexistent/plugin.so") != 0
     assert b"cannot load plug-in" in L.cmdg_last_error(None)
+
+
+def test_plugin_built_against_other_headers_is_refused(tmp_path):
+    """A plug-in shares the C++ layout of the engine base class with the library (cmdg_plugin_abi);
+    one whose stamp differs -- or that has none -- is refused at load with the reason."""
+    import ctypes as C
+    import subprocess
+    from cmdg_loader import cm
+    L = cm._lib.lib()
+    L.cmdg_last_error.restype = C.c_char_p
+    for name, body, reason in (
+            ("stale", "unsigned long cmdg_plugin_abi(void) { return 1; }", b"another libcmdg"),
+            ("unstamped", "", b"does not export cmdg_plugin_abi")):
+        src = tmp_path / (name + ".c")
+        src.write_text("void *cmdg_plugin_make_engine(const void *d, char *e, int n) { return 0; }\n" + body + "\n")
+        so = tmp_path / (name + ".so")
+        subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+        assert L.cmdg_load_plugin(str(so).encode()) != 0
+        assert reason in L.cmdg_last_error(None), L.cmdg_last_error(None)
