@@ -140,6 +140,7 @@ class DGModel:
         (``cmdg_export_gradient_flux``: a copy out of the node-major working array for the
         atmosphere laws, the working array itself otherwise)."""
         if self.balance_law.ngradflux > 0:
+            self._torch_ready()
             _lib.check(self.L.cmdg_export_gradient_flux(self.handle, self._gradient_flux.data_ptr()), self.handle)
         return self._gradient_flux
 
@@ -153,6 +154,7 @@ class DGModel:
             self._hypervisc_grad = torch.zeros((g.nelem, max(3 * law.ngradlap, 1), g.Np), dtype=torch.float64,
                                                device=self.device)
         if law.ngradlap > 0:
+            self._torch_ready()      # (the fill of a fresh destination runs on torch's stream, the copy on ours)
             _lib.check(self.L.cmdg_export_hypervisc_grad(self.handle, self._hypervisc_grad.data_ptr()), self.handle)
         return self._hypervisc_grad
 

@@ -292,7 +292,9 @@ int cmdg_query(cmdg_handle h, int32_t what, int64_t *out);
  * the Laplacian and tendency passes reads -- so cmdg_desc.Qhypervisc_grad is
  * NOT written by an evaluation; this call writes the array as the reference would hold it after
  * the last evaluation (`dst`, or cmdg_desc.Qhypervisc_grad if dst is NULL) and returns when the
- * copy is complete.  Ghost elements as described for CMDG_OPT_REFERENCE_HALO.  For diagnostics
+ * copy is complete.  The copy runs on the handle's own (non-blocking) stream: work the caller has
+ * pending on `dst` on another stream -- the fill of a freshly allocated array -- must have finished
+ * before the call.  Ghost elements as described for CMDG_OPT_REFERENCE_HALO.  For diagnostics
  * and tests: nothing on the hot path reads the reference layout. */
 int cmdg_export_hypervisc_grad(cmdg_handle h, double *dst);
 /* The same for dg.state_gradient_flux, (Np, ngradflux, nelem).  For the dry atmosphere (physics_id 2)
